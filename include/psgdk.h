@@ -1,0 +1,138 @@
+/*
+ * psgdk.h -- C ABI of the MI355X-native PSGD preconditioner engine (libpsgdk.so).
+ *
+ * This is the drop-in boundary for ONE hot path of lixilinx/psgd_torch: the Kron "Q0.5EQ1.5" whitening
+ * preconditioner update + apply (and, secondarily, the LRA update + apply).  The reference has no FFI -- its seam
+ * is three Python functions selected at wrapped_as_torch_optimizer_for_ddp.py:84-86 plus psgd.init_kron
+ * (..._ddp.py:131-135).  Each entry point below names the reference code it replaces (file:line under the
+ * reference repo).  All pointers are raw device pointers (or host arrays of device pointers where stated);
+ * no torch types cross this boundary.  Every call is stream-ordered on `stream` (a hipStream_t passed as void*),
+ * performs no hidden host synchronisation, never frees or allocates caller memory, and returns an int status
+ * (no C++ exceptions cross the ABI).
+ *
+ * Differences from the reference seam, on purpose (MI355X-first):
+ *   - calls are BATCHED over all tensors of a plan (one grouped launch per stage instead of ~100 ATen launches
+ *     per tensor); a 1-tensor plan gives the reference's per-tensor functional behaviour;
+ *   - randomness is explicit: either caller-supplied noise buffers (parity testing) or a counter-based Philox
+ *     stream (seed, offset), so replicas stay identical without broadcasting RNG state (..._ddp.py:88-104);
+ *   - state lives in two caller-allocated arenas (persistent `state`, scratch `work`) whose layout the plan
+ *     defines: every matrix is zero-padded to multiples of 64 in both dims, each dense factor Q is stored together
+ *     with its transpose Qt, and a 2-D tensor with exactly one dense factor is held with the dense dim last.
+ */
+#ifndef PSGDK_H
+#define PSGDK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSGDK_VERSION 100
+
+/* status codes */
+enum {
+    PSGDK_OK = 0,
+    PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
+    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (e.g. tensors with > 2 non-singleton dims) */
+    PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
+    PSGDK_ERR_STATE = 4        /* call order violated (e.g. arenas not bound) */
+};
+
+/* element types */
+enum { PSGDK_BF16 = 0, PSGDK_F32 = 1 };
+/* factor kinds, psgd.py:208 */
+enum { PSGDK_DIAG = 0, PSGDK_DENSE = 1, PSGDK_SCALAR = 2 };
+/* which buffer a stage reads: the momentum EMA or the (cast) gradient, ..._ddp.py:145,150 */
+enum { PSGDK_SRC_EMA = 0, PSGDK_SRC_GRAD = 1 };
+
+typedef struct psgdk_plan psgdk_plan;
+
+int psgdk_version(void);
+const char* psgdk_strerror(int status);
+int psgdk_last_hip_error(void);
+
+/* ---- planning: replaces psgd.init_kron's structural half (psgd.py:161-263, dense/diag rule psgd.py:208) -----
+ * n_tensors tensors; tensor t has ndim[t] dims (AFTER squeeze(), ..._ddp.py:124) listed consecutively in `dims`.
+ * precond_dtype: PSGDK_BF16 | PSGDK_F32 (..._ddp.py:41,58).  use_momentum: allocate the EMA buffers (..._ddp.py:137).
+ * Tensors with more than 26 dims -> PSGDK_ERR_INVALID (psgd.py:197-198); with > 2 dims -> PSGDK_ERR_UNSUPPORTED. */
+int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, const int64_t* dims, double max_size,
+                      double max_skew, int precond_dtype, int use_momentum);
+int psgdk_plan_destroy(psgdk_plan* plan);
+
+/* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
+int psgdk_plan_arena_bytes(const psgdk_plan* plan, size_t* state_bytes, size_t* work_bytes);
+int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena);
+
+/* introspection so the host can expose Q / L / ema as strided views of the state arena (the reference keeps them in
+ * optimizer.state[p]["QL"], ["ema"], ..._ddp.py:129-137).  Offsets are bytes from the state arena base.
+ * Dense factor: rows = cols = d, row stride `ld` elements.  Diag/scalar factor: rows = 1, cols = d. */
+int psgdk_plan_num_factors(const psgdk_plan* plan, int t, int* n_factors);
+int psgdk_plan_factor_view(const psgdk_plan* plan, int t, int i, int* kind, size_t* q_offset, int64_t* d,
+                           int64_t* ld, size_t* lipschitz_offset);
+/* EMA view: logical shape (rows, cols) of the squeezed tensor; element (r, c) lives at
+ * offset + (transposed ? c*ld + r : r*ld + c) * elem_size. */
+int psgdk_plan_ema_view(const psgdk_plan* plan, int t, size_t* offset, int64_t* rows, int64_t* cols, int64_t* ld,
+                        int* transposed);
+
+/* ---- init_kron's numeric half (psgd.py:200,207,210,228): Q_i = scale^(1/k) I | ones, L_i = 0, ema = 0 ------ */
+int psgdk_init_state(psgdk_plan* plan, double scale, void* stream);
+/* after the HOST wrote into Q views (load_state_dict, tests): rebuild the internal transposes / cached P. */
+int psgdk_state_changed(psgdk_plan* plan, void* stream);
+
+/* ---- momentum + cast: replaces ..._ddp.py:117-143 (coupled weight decay, squeeze+cast, EMA with warm-up beta) --
+ * grads/params: HOST arrays of n_tensors DEVICE pointers (contiguous tensors in their logical layout; params may be
+ * NULL when coupled_wd == 0).  beta = min(t/(t+1), momentum) is computed by the caller per ..._ddp.py:141.
+ * Produces ema <- beta*ema + (1-beta)*cast(g + coupled_wd*p) (if the plan has momentum) and keeps cast(g) for
+ * PSGDK_SRC_GRAD consumers. */
+int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
+                     int param_dtype, float coupled_wd, float beta, void* stream);
+
+/* explicit noise for parity testing (all device pointers, element type = precond dtype, logical layouts):
+ *   g_noise[t]            : numel(t) values, the randn_like(G) of psgd.py:403
+ *   spd_noise[t*2+i]      : 32 x d_i values, the randn(32,d) of psgd.py:62 for dense factor i of tensor t
+ *   skh_noise[t*2+i]      : 32 x d_i values, the randn(32,d) of psgd.py:87
+ * A NULL psgdk_noise* selects the built-in Philox4x32-10 stream keyed by (seed, offset). */
+typedef struct psgdk_noise {
+    const void* const* g_noise;
+    const void* const* spd_noise;
+    const void* const* skh_noise;
+} psgdk_noise;
+
+/* ---- replaces psgd.update_precond_kron_whiten_q0p5eq1p5 (psgd.py:394-419) with its helpers
+ * norm_lower_bound_spd (psgd.py:46-68), procrustes_step2 (psgd.py:101-124) -> norm_lower_bound_skh (psgd.py:71-93),
+ * balance_kron_precond (psgd.py:266-275).  In place on Q and L of every tensor of the plan.
+ * balance_mask: HOST array of n_tensors bytes; nonzero = the caller's rand([]) < 0.01 draw (psgd.py:418) fired for
+ * that tensor (NULL = never). */
+int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                                   const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                                   const uint8_t* balance_mask, void* stream);
+
+/* ---- replaces psgd.precond_grad_kron (psgd.py:322-327): h_t = (kron_i Q_i^T Q_i) src_t for every tensor; h stays
+ * in the work arena (consumed by psgdk_apply_update / psgdk_read_precond_grad). */
+int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream);
+
+/* ---- replaces ..._ddp.py:117-120 (decoupled weight decay) and 153-157 (RMS clip, element clip, p -= lr*h) ----
+ * params: HOST array of n_tensors DEVICE pointers (logical layout). */
+int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, float lr, float decoupled_wd,
+                       float max_avg_amp, float max_elem_amp, void* stream);
+
+/* copy h of tensor t to `out` (logical layout, contiguous, out_dtype) -- the return value of precond_grad_kron.
+ * clip != 0 applies the ..._ddp.py:153-156 clipping first (used by the sharded path to ship clipped h). */
+int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,
+                            float max_elem_amp, void* stream);
+
+/* fill `out` with the engine's N(0,1) stream (same generator the fused kernels use), for statistical tests. */
+int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
+                      void* stream);
+
+/* ---- kernel-level test hooks (used by tests/ and bench.py only) ------------------------------------------------
+ * C[M,N] = A[M,K] * B[N,K]^T on padded row-major operands (all dims multiples of 64), same kernel the engine uses. */
+int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,
+                       int ldb, int ldc, int ldct, int symmetric, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSGDK_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libpsgdk.so (include/psgdk.h).  There is NO fallback: if the HIP library is missing or a
+call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
+
+PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE = 0, 1, 2, 3, 4
+BF16, F32 = 0, 1
+DIAG, DENSE, SCALAR = 0, 1, 2
+SRC_EMA, SRC_GRAD = 0, 1
+
+
+class PsgdkError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(what)
+
+
+class Noise(C.Structure):
+    _fields_ = [("g_noise", C.POINTER(C.c_void_p)), ("spd_noise", C.POINTER(C.c_void_p)),
+                ("skh_noise", C.POINTER(C.c_void_p))]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/psgdk.h declares
+SIGNATURES = {
+    "psgdk_version": (C.c_int, []),
+    "psgdk_strerror": (C.c_char_p, [C.c_int]),
+    "psgdk_last_hip_error": (C.c_int, []),
+    "psgdk_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                    C.c_double, C.c_double, C.c_int, C.c_int]),
+    "psgdk_plan_destroy": (C.c_int, [C.c_void_p]),
+    "psgdk_plan_arena_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "psgdk_plan_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psgdk_plan_num_factors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "psgdk_plan_factor_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]),
+    "psgdk_plan_ema_view": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "psgdk_init_state": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "psgdk_state_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "psgdk_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                   C.c_float, C.c_float, C.c_void_p]),
+    "psgdk_update_precond_q0p5eq1p5": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                 C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8),
+                                                 C.c_void_p]),
+    "psgdk_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "psgdk_apply_update": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_void_p]),
+    "psgdk_read_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                          C.c_void_p]),
+    "psgdk_fill_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def lib():
+    """Loads libpsgdk.so (importing torch first so that the HIP runtime already in the process is reused)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsgdkError(-1, f"{LIB_PATH} is missing: build it with `python -m psgd_torch_amd.build` "
+                             "(there is no CPU fallback for the HIP engine)")
+    import torch  # noqa: F401  (loads libamdhip64.so.7 so the same runtime instance serves both)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status != PSGDK_OK:
+        L = lib()
+        msg = L.psgdk_strerror(status).decode()
+        if status == PSGDK_ERR_HIP:
+            msg += f" (hipError {L.psgdk_last_hip_error()})"
+        raise PsgdkError(status, f"psgdk: {what}: {msg}")
+
+
+def dtype_code(dt):
+    import torch
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise PsgdkError(PSGDK_ERR_INVALID, f"unsupported dtype {dt} (bf16 and fp32 only)")
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
