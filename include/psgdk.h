@@ -84,10 +84,10 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream);
 /* ---- momentum + cast: replaces ..._ddp.py:117-143 (coupled weight decay, squeeze+cast, EMA with warm-up beta) --
  * grads/params: HOST arrays of n_tensors DEVICE pointers (contiguous tensors in their logical layout; params may be
  * NULL when coupled_wd == 0).  beta = min(t/(t+1), momentum) is computed by the caller per ..._ddp.py:141.
- * Produces ema <- beta*ema + (1-beta)*cast(g + coupled_wd*p) (if the plan has momentum) and keeps cast(g) for
- * PSGDK_SRC_GRAD consumers. */
+ * Produces ema <- beta*ema + (1-beta)*cast(g + coupled_wd*p) (if the plan has momentum); keep_grad != 0 (forced when
+ * the plan has no momentum) also keeps cast(g) for PSGDK_SRC_GRAD consumers (whiten_grad=True, ..._ddp.py:145). */
 int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
-                     int param_dtype, float coupled_wd, float beta, void* stream);
+                     int param_dtype, float coupled_wd, float beta, int keep_grad, void* stream);
 
 /* explicit noise for parity testing (all device pointers, element type = precond dtype, logical layouts):
  *   g_noise[t]            : numel(t) values, the randn_like(G) of psgd.py:403

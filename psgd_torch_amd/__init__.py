@@ -1,0 +1,12 @@
+"""psgd_torch_amd -- MI355X-native engine for the PSGD Kron/LRA preconditioner hot path of lixilinx/psgd_torch.
+
+Public surface (mirrors the reference's names for this path):
+    KWNS4                                       torch.optim.Optimizer (wrapped_as_torch_optimizer_for_ddp.py:4)
+    init_kron, update_precond_kron_whiten_q0p5eq1p5, precond_grad_kron      functional seam (psgd.py:161,394,322)
+Everything computes through libpsgdk.so (hand-written HIP for gfx950, include/psgdk.h); there is no CPU fallback.
+"""
+from .kron import init_kron, precond_grad_kron, update_precond_kron_whiten_q0p5eq1p5  # noqa: F401
+from .kwns4 import KWNS4  # noqa: F401
+from .engine import KronEngine  # noqa: F401
+
+__all__ = ["KWNS4", "KronEngine", "init_kron", "update_precond_kron_whiten_q0p5eq1p5", "precond_grad_kron"]

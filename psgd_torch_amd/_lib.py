@@ -43,7 +43,7 @@ SIGNATURES = {
     "psgdk_init_state": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "psgdk_state_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psgdk_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int,
-                                   C.c_float, C.c_float, C.c_void_p]),
+                                   C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "psgdk_update_precond_q0p5eq1p5": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                                  C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8),
                                                  C.c_void_p]),

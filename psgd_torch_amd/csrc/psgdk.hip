@@ -1,6 +1,107 @@
 // psgdk.hip -- C-ABI implementation (see include/psgdk.h).  One translation unit; kernels live in the .hiph files.
+//
+// A plan lays every tensor of an optimizer (or one tensor, for the functional seam) out in two caller-owned arenas
+// and pre-builds, once, the grouped-GEMM problem/tile tables of every stage.  A step is then ~30 grouped launches
+// over ALL tensors (the reference issues ~100 ATen launches per tensor), with every scalar kept on the device.
 #include "host_util.hiph"
+#include "descs.hiph"
 #include "kernels_ew.hiph"
+#include "kernels_dense.hiph"
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace {
+
+struct Stage {                       // one grouped GEMM launch
+    std::vector<GemmProblem> probs;
+    GemmProblem* d_probs = nullptr;
+    GemmTile* d_tiles = nullptr;
+    unsigned n_tiles = 0;
+};
+
+struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
+
+}  // namespace
+
+struct psgdk_plan {
+    int n_tensors = 0, dtype = 0, use_momentum = 0;
+    size_t esz = 2;
+    double max_size = 0, max_skew = 0;
+    std::vector<TensorDesc> td;
+    std::vector<DiagDesc> dd;
+    std::vector<DenseDesc> dn;
+    std::vector<std::vector<FactorRef>> factors;    // per tensor, logical dim order
+    std::vector<int> order;                          // number of factors per tensor (k of scale^(1/k))
+    std::vector<int> dense_dim;                      // per dense factor: logical dim index (0/1)
+    size_t state_bytes = 0, work_bytes = 0;
+    size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0;
+    unsigned char* state = nullptr;
+    unsigned char* work = nullptr;
+    // device tables owned by the plan
+    TensorDesc* d_td = nullptr; DiagDesc* d_dd = nullptr; DenseDesc* d_dn = nullptr;
+    EwTile* d_tiles_all = nullptr; unsigned n_tiles_all = 0;
+    std::vector<unsigned> tile_begin;                // per tensor range in d_tiles_all
+    EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
+    void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
+    void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
+    float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
+    int* d_balance = nullptr;
+    int max_dp = 0;
+    bool p_valid = false;
+    Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b;
+    std::vector<int> split_dense;                    // dense factors whose Gram is split-K
+
+    ~psgdk_plan() {
+        auto fr = [](void* p) { if (p) (void)hipFree(p); };
+        fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
+        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance);
+        for (Stage* s : {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b}) {
+            fr(s->d_probs); fr(s->d_tiles);
+        }
+    }
+};
+
+namespace {
+
+template <typename X>
+int upload(X** dst, const std::vector<X>& v) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    if (v.empty()) return PSGDK_OK;
+    HIPCHK(hipMalloc((void**)dst, v.size() * sizeof(X)));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(X), hipMemcpyHostToDevice));
+    return PSGDK_OK;
+}
+
+int finish_stage(Stage& s) {
+    TileTableBuilder tb;
+    for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
+    std::vector<GemmTile> tiles = tb.finish();
+    s.n_tiles = (unsigned)tiles.size();
+    int rc = upload(&s.d_probs, s.probs);
+    if (rc) return rc;
+    return upload(&s.d_tiles, tiles);
+}
+
+template <typename T>
+void launch_stage_t(const Stage& s, hipStream_t st) {
+    if (s.n_tiles) hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
+}
+void launch_stage(const psgdk_plan* p, const Stage& s, hipStream_t st) {
+    if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st);
+}
+
+#define DISPATCH_T(plan, CALL)                         \
+    do {                                               \
+        if ((plan)->dtype == PSGDK_BF16) { typedef bf16_t T; CALL; } else { typedef float T; CALL; } \
+    } while (0)
+
+bool is_dense_dim(int64_t size, int64_t numel, double max_size, double max_skew) {
+    // psgd.py:208  -- diagonal iff size <= 1 or size > max_size or size**2 > max_skew * numel
+    return !(size <= 1 || (double)size > max_size || (double)size * (double)size > max_skew * (double)numel);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -19,6 +120,505 @@ const char* psgdk_strerror(int status) {
 
 int psgdk_last_hip_error(void) { return g_last_hip_error; }
 
+int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, const int64_t* dims, double max_size,
+                      double max_skew, int precond_dtype, int use_momentum) {
+    if (!out || n_tensors <= 0 || !ndim || (precond_dtype != PSGDK_BF16 && precond_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (!(max_size >= 0.0) || !(max_skew >= 0.0)) return PSGDK_ERR_INVALID;
+    std::unique_ptr<psgdk_plan> P(new psgdk_plan());
+    P->n_tensors = n_tensors; P->dtype = precond_dtype; P->use_momentum = use_momentum ? 1 : 0;
+    P->esz = precond_dtype == PSGDK_BF16 ? 2 : 4;
+    P->max_size = max_size; P->max_skew = max_skew;
+    const size_t esz = P->esz;
+    size_t dpos = 0;
+    // ---- structure (init_kron's dense/diag rule) ----
+    for (int t = 0; t < n_tensors; ++t) {
+        const int nd = ndim[t];
+        if (nd < 0 || nd > 26) return PSGDK_ERR_INVALID;           // psgd.py:197-198
+        if (nd > 0 && !dims) return PSGDK_ERR_INVALID;
+        int64_t numel = 1;
+        for (int i = 0; i < nd; ++i) { if (dims[dpos + i] <= 0) return PSGDK_ERR_INVALID; numel *= dims[dpos + i]; }
+        if (nd > 2) return PSGDK_ERR_UNSUPPORTED;
+        TensorDesc D{};
+        D.numel = numel; D.row_diag = D.col_diag = D.row_dense = D.col_dense = -1;
+        std::vector<FactorRef> fr;
+        if (nd <= 1) {
+            const int64_t n = nd == 0 ? 1 : dims[dpos];
+            // a 1-D tensor of size n: dense iff n^2 <= max_skew * n (psgd.py:208) -- only possible for tiny n / huge skew
+            const bool dense = nd == 1 && is_dense_dim(n, numel, max_size, max_skew);
+            D.lrows = 1; D.lcols = (int)n; D.transposed = 0; D.R = 1; D.C = (int)n;
+            if (dense) {
+                // treat as an R=1 row with a dense column factor: reuse the matrix path (TK_M1 without row factor)
+                D.kind = TK_M1; D.Rp = 64; D.Cp = (int)round_up64(n);
+            } else {
+                D.kind = TK_VEC; D.Rp = 1; D.Cp = (int)round_up64(n);
+            }
+            fr.push_back(FactorRef{dense ? PSGDK_DENSE : (nd == 0 ? PSGDK_SCALAR : PSGDK_DIAG), -1});
+        } else {
+            const int64_t m = dims[dpos], n = dims[dpos + 1];
+            const bool d0 = is_dense_dim(m, numel, max_size, max_skew), d1 = is_dense_dim(n, numel, max_size, max_skew);
+            D.lrows = (int)m; D.lcols = (int)n;
+            D.transposed = (d0 && !d1) ? 1 : 0;
+            D.R = D.transposed ? (int)n : (int)m; D.C = D.transposed ? (int)m : (int)n;
+            D.Rp = (int)round_up64(D.R); D.Cp = (int)round_up64(D.C);
+            D.kind = (d0 && d1) ? TK_M2 : ((d0 || d1) ? TK_M1 : TK_DD);
+            fr.push_back(FactorRef{d0 ? PSGDK_DENSE : PSGDK_DIAG, -1});
+            fr.push_back(FactorRef{d1 ? PSGDK_DENSE : PSGDK_DIAG, -1});
+        }
+        P->td.push_back(D);
+        P->factors.push_back(fr);
+        P->order.push_back(nd == 0 ? 1 : nd);
+        dpos += nd;
+    }
+    // ---- factor lists ----
+    for (int t = 0; t < n_tensors; ++t) {
+        TensorDesc& D = P->td[t];
+        auto& fr = P->factors[t];
+        for (size_t i = 0; i < fr.size(); ++i) {
+            // which canonical side does logical dim i sit on?
+            bool is_row;
+            if (fr.size() == 1) is_row = false;                  // vectors / scalars: the column side
+            else is_row = D.transposed ? (i == 1) : (i == 0);
+            const int len = is_row ? D.R : D.C;
+            if (fr[i].kind == PSGDK_DENSE) {
+                DenseDesc F{};
+                F.tensor = t; F.d = len; F.dp = (int)round_up64(len); F.is_row = is_row ? 1 : 0;
+                F.c = (float)((double)D.numel / (double)len);
+                fr[i].idx = (int)P->dn.size();
+                (is_row ? D.row_dense : D.col_dense) = fr[i].idx;
+                P->dn.push_back(F);
+                P->dense_dim.push_back((int)i);
+                P->max_dp = std::max(P->max_dp, F.dp);
+            } else {
+                DiagDesc G{};
+                G.tensor = t; G.len = len; G.is_row = is_row ? 1 : 0;
+                G.c = (float)((double)D.numel / (double)len);
+                fr[i].idx = (int)P->dd.size();
+                (is_row ? D.row_diag : D.col_diag) = fr[i].idx;
+                P->dd.push_back(G);
+            }
+        }
+    }
+    // ---- state arena: [L fp32 per factor][diag vectors][Q, Qt][ema] ----
+    size_t so = 0;
+    for (auto& G : P->dd) { G.L_off = so; so += 4; }
+    for (auto& F : P->dn) { F.L_off = so; so += 4; }
+    so = align256(so);
+    for (auto& G : P->dd) { G.a_off = so; so += align256((size_t)round_up64(G.len) * esz); }
+    for (auto& F : P->dn) {
+        const size_t mb = align256((size_t)F.dp * F.dp * esz);
+        F.q_off = so; so += mb; F.qt_off = so; so += mb;
+    }
+    for (auto& D : P->td) {
+        D.ema_off = so;
+        if (P->use_momentum) so += align256((size_t)D.Rp * D.Cp * esz);
+    }
+    P->state_bytes = align256(so);
+    // ---- work arena ----
+    size_t wo = 0;
+    P->zero_off = wo;
+    for (auto& F : P->dn) { F.sc_off = wo; wo += 64; }
+    wo = align256(wo);
+    for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
+    P->zero_bytes = wo - P->zero_off;
+    P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
+    for (auto& D : P->td) {
+        const size_t mb = align256((size_t)D.Rp * D.Cp * esz);
+        D.gc_off = wo; wo += mb; D.x_off = wo; wo += mb; D.h_off = wo; wo += mb;
+        if (D.kind == TK_M1 || D.kind == TK_M2) { D.pgt_off = wo; wo += mb; }
+        if (D.kind == TK_M2) { D.pg_off = wo; wo += mb; D.tt_off = wo; wo += mb; }
+    }
+    for (auto& F : P->dn) {
+        const size_t mb = align256((size_t)F.dp * F.dp * esz);
+        size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off, &F.rrq_off, &F.rrqt_off};
+        for (size_t* o : offs) { *o = wo; wo += mb; }
+        F.va_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
+        F.vb_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
+        F.rowss_off = wo; wo += align256((size_t)F.dp * 4);
+        // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
+        const TensorDesc& D = P->td[F.tensor];
+        const int K = F.is_row ? D.Cp : D.Rp;
+        F.slab_off = 0;
+        if (K > 4096) {
+            const int nks = (K + 3071) / 3072;
+            F.slab_off = wo; wo += align256((size_t)nks * F.dp * F.dp * 4);
+        }
+    }
+    P->work_bytes = align256(wo);
+    *out = P.release();
+    return PSGDK_OK;
+}
+
+int psgdk_plan_destroy(psgdk_plan* plan) {
+    delete plan;
+    return PSGDK_OK;
+}
+
+int psgdk_plan_arena_bytes(const psgdk_plan* plan, size_t* state_bytes, size_t* work_bytes) {
+    if (!plan || !state_bytes || !work_bytes) return PSGDK_ERR_INVALID;
+    *state_bytes = plan->state_bytes; *work_bytes = plan->work_bytes;
+    return PSGDK_OK;
+}
+
+int psgdk_plan_num_factors(const psgdk_plan* plan, int t, int* n_factors) {
+    if (!plan || t < 0 || t >= plan->n_tensors || !n_factors) return PSGDK_ERR_INVALID;
+    *n_factors = (int)plan->factors[t].size();
+    return PSGDK_OK;
+}
+
+int psgdk_plan_factor_view(const psgdk_plan* plan, int t, int i, int* kind, size_t* q_offset, int64_t* d, int64_t* ld,
+                           size_t* lipschitz_offset) {
+    if (!plan || t < 0 || t >= plan->n_tensors || i < 0 || i >= (int)plan->factors[t].size()) return PSGDK_ERR_INVALID;
+    const FactorRef& fr = plan->factors[t][i];
+    if (kind) *kind = fr.kind;
+    if (fr.kind == PSGDK_DENSE) {
+        const DenseDesc& F = plan->dn[fr.idx];
+        if (q_offset) *q_offset = F.q_off;
+        if (d) *d = F.d;
+        if (ld) *ld = F.dp;
+        if (lipschitz_offset) *lipschitz_offset = F.L_off;
+    } else {
+        const DiagDesc& G = plan->dd[fr.idx];
+        if (q_offset) *q_offset = G.a_off;
+        if (d) *d = G.len;
+        if (ld) *ld = G.len;
+        if (lipschitz_offset) *lipschitz_offset = G.L_off;
+    }
+    return PSGDK_OK;
+}
+
+int psgdk_plan_ema_view(const psgdk_plan* plan, int t, size_t* offset, int64_t* rows, int64_t* cols, int64_t* ld,
+                        int* transposed) {
+    if (!plan || t < 0 || t >= plan->n_tensors) return PSGDK_ERR_INVALID;
+    if (!plan->use_momentum) return PSGDK_ERR_STATE;
+    const TensorDesc& D = plan->td[t];
+    if (offset) *offset = D.ema_off;
+    if (rows) *rows = D.lrows;
+    if (cols) *cols = D.lcols;
+    if (ld) *ld = D.Cp;
+    if (transposed) *transposed = D.transposed;
+    return PSGDK_OK;
+}
+
+int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
+    if (!plan || !state_arena || !work_arena) return PSGDK_ERR_INVALID;
+    if (((uintptr_t)state_arena & 255) || ((uintptr_t)work_arena & 255)) return PSGDK_ERR_INVALID;
+    psgdk_plan* P = plan;
+    P->state = (unsigned char*)state_arena; P->work = (unsigned char*)work_arena;
+    P->p_valid = false;
+    unsigned char* S = P->state; unsigned char* W = P->work;
+    int rc;
+    if ((rc = upload(&P->d_td, P->td))) return rc;
+    if ((rc = upload(&P->d_dd, P->dd))) return rc;
+    if ((rc = upload(&P->d_dn, P->dn))) return rc;
+    // ---- elementwise tile tables ----
+    std::vector<EwTile> all, diag;
+    P->tile_begin.assign(P->n_tensors + 1, 0);
+    for (int t = 0; t < P->n_tensors; ++t) {
+        const TensorDesc& D = P->td[t];
+        P->tile_begin[t] = (unsigned)all.size();
+        for (int tr = 0; tr < (D.R + 63) / 64; ++tr)
+            for (int tc = 0; tc < (D.C + 63) / 64; ++tc) {
+                all.push_back(EwTile{t, tr, tc});
+                if (D.kind == TK_VEC || D.kind == TK_DD) diag.push_back(EwTile{t, tr, tc});
+            }
+    }
+    P->tile_begin[P->n_tensors] = (unsigned)all.size();
+    P->n_tiles_all = (unsigned)all.size(); P->n_tiles_diag = (unsigned)diag.size();
+    if ((rc = upload(&P->d_tiles_all, all))) return rc;
+    if ((rc = upload(&P->d_tiles_diag, diag))) return rc;
+    auto alloc_ptrs = [&](void*** p, size_t n) -> int {
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+        HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(void*)));
+        return PSGDK_OK;
+    };
+    if ((rc = alloc_ptrs(&P->d_ptr_a, P->n_tensors))) return rc;
+    if ((rc = alloc_ptrs(&P->d_ptr_b, P->n_tensors))) return rc;
+    if ((rc = alloc_ptrs(&P->d_noise_g, P->n_tensors))) return rc;
+    if ((rc = alloc_ptrs(&P->d_noise_spd, P->dn.size()))) return rc;
+    if ((rc = alloc_ptrs(&P->d_noise_skh, P->dn.size()))) return rc;
+    if (P->d_balance) { (void)hipFree(P->d_balance); P->d_balance = nullptr; }
+    HIPCHK(hipMalloc((void**)&P->d_balance, P->n_tensors * sizeof(int)));
+    if (P->d_scale_diag) { (void)hipFree(P->d_scale_diag); P->d_scale_diag = nullptr; }
+    if (P->d_scale_dense) { (void)hipFree(P->d_scale_dense); P->d_scale_dense = nullptr; }
+    HIPCHK(hipMalloc((void**)&P->d_scale_diag, std::max<size_t>(P->dd.size(), 1) * 4));
+    HIPCHK(hipMalloc((void**)&P->d_scale_dense, std::max<size_t>(P->dn.size(), 1) * 4));
+
+    // ---- grouped GEMM stages (absolute pointers, so built at bind time) ----
+    for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1], &P->g_app_b})
+        s->probs.clear();
+    P->split_dense.clear();
+    float* hsumsq = (float*)(W + P->hsumsq_off);
+    for (size_t f = 0; f < P->dn.size(); ++f) {
+        const DenseDesc& F = P->dn[f];
+        const TensorDesc& D = P->td[F.tensor];
+        float* sc = (float*)(W + F.sc_off);
+        GemmProblem g{};
+        // P = Q^T Q = Qt Qt^T
+        g.A = S + F.qt_off; g.B = S + F.qt_off; g.C = W + F.p_off; g.Ct = g.C;
+        g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
+        P->g_P.probs.push_back(g);
+        // mode Gram term1 (psgd.py:405): col factor: Pgt Pgt^T; row factor: Pg Pg^T
+        g = GemmProblem{};
+        const unsigned char* Z = W + (F.is_row ? D.pg_off : D.pgt_off);
+        const int K = F.is_row ? D.Cp : D.Rp;
+        g.A = Z; g.B = Z; g.C = W + F.t1_off; g.Ct = g.C;
+        g.M = g.N = F.dp; g.K = K; g.lda = g.ldb = K; g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
+        if (F.slab_off) {
+            g.flags |= GF_SPLITK; g.kchunk = 3072; g.slab = (float*)(W + F.slab_off);
+            P->split_dense.push_back((int)f);
+        }
+        P->g_gram.probs.push_back(g);
+        // Q' = Q - mu (term1 Q - c Q)   (psgd.py:415)
+        g = GemmProblem{};
+        g.A = W + F.t1_off; g.B = S + F.qt_off; g.C = W + F.qn_off; g.Ct = W + F.qtn_off;
+        g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = g.ldq = F.dp; g.alpha = 1.f;
+        g.flags = GF_QUPD; g.Qold = S + F.q_off; g.mu_dev = sc + DS_MU; g.c = F.c;
+        P->g_qupd.probs.push_back(g);
+        // RQ = s R Q', RRQ = s R RQ  (psgd.py:118-120), traces for the line search (psgd.py:121-122)
+        g = GemmProblem{};
+        g.A = W + F.r_off; g.B = W + F.qtn_off; g.C = W + F.rq_off; g.Ct = W + F.rqt_off;
+        g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.alpha_dev = sc + DS_S; g.trace = sc + DS_TR1;
+        P->g_rq.probs.push_back(g);
+        g.B = W + F.rqt_off; g.C = W + F.rrq_off; g.Ct = W + F.rrqt_off; g.trace = sc + DS_TR2;
+        P->g_rrq.probs.push_back(g);
+    }
+    for (int t = 0; t < P->n_tensors; ++t) {
+        const TensorDesc& D = P->td[t];
+        if (D.kind != TK_M1 && D.kind != TK_M2) continue;
+        const DenseDesc& Fc = P->dn[D.col_dense];
+        const void* rs = D.row_diag >= 0 ? (const void*)(S + P->dd[D.row_diag].a_off) : nullptr;
+        float* rsum = D.row_diag >= 0 ? (float*)(W + P->dd[D.row_diag].sum_off) : nullptr;
+        // first product: S * P_col (S = X for the update, ema / grad for the apply)
+        GemmProblem g{};
+        g.B = W + Fc.p_off; g.M = D.Rp; g.N = D.Cp; g.K = D.Cp; g.lda = D.Cp; g.ldb = Fc.dp; g.alpha = 1.f;
+        if (D.kind == TK_M1) {
+            g.row_scale = rs; g.flags = rs ? GF_SQ_ROWSCALE : 0;
+            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.pgt_off; u.ldct = D.Rp; u.row_sumsq = rsum;
+            P->g_upd_a.probs.push_back(u);
+            for (int src = 0; src < 2; ++src) {
+                GemmProblem a = g; a.A = src == PSGDK_SRC_GRAD ? (const void*)(W + D.gc_off) : (const void*)(S + D.ema_off);
+                a.C = W + D.h_off; a.ldc = D.Cp; a.sumsq = hsumsq + t;
+                P->g_app_a[src].probs.push_back(a);
+            }
+        } else {
+            const DenseDesc& Fr = P->dn[D.row_dense];
+            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.tt_off; u.ldct = D.Rp;
+            P->g_upd_a.probs.push_back(u);
+            for (int src = 0; src < 2; ++src) {
+                GemmProblem a = g; a.A = src == PSGDK_SRC_GRAD ? (const void*)(W + D.gc_off) : (const void*)(S + D.ema_off);
+                a.Ct = W + D.tt_off; a.ldct = D.Rp;
+                P->g_app_a[src].probs.push_back(a);
+            }
+            // second product: P_row * T, via T^T as the K-contiguous B operand
+            GemmProblem b{};
+            b.A = W + Fr.p_off; b.B = W + D.tt_off; b.M = D.Rp; b.N = D.Cp; b.K = D.Rp; b.lda = Fr.dp; b.ldb = D.Rp; b.alpha = 1.f;
+            GemmProblem ub = b; ub.C = W + D.pg_off; ub.ldc = D.Cp; ub.Ct = W + D.pgt_off; ub.ldct = D.Rp;
+            P->g_upd_b.probs.push_back(ub);
+            GemmProblem ab = b; ab.C = W + D.h_off; ab.ldc = D.Cp; ab.sumsq = hsumsq + t;
+            P->g_app_b.probs.push_back(ab);
+        }
+    }
+    for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1], &P->g_app_b})
+        if ((rc = finish_stage(*s))) return rc;
+    return PSGDK_OK;
+}
+
+int psgdk_init_state(psgdk_plan* plan, double scale, void* stream) {
+    if (!plan || !(scale > 0.0)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(plan->state, 0, plan->state_bytes, st));
+    std::vector<float> sd(plan->dd.size()), sn(plan->dn.size());
+    for (size_t i = 0; i < plan->dd.size(); ++i) sd[i] = (float)std::pow(scale, 1.0 / plan->order[plan->dd[i].tensor]);
+    for (size_t i = 0; i < plan->dn.size(); ++i) sn[i] = (float)std::pow(scale, 1.0 / plan->order[plan->dn[i].tensor]);
+    if (!sd.empty()) HIPCHK(hipMemcpyAsync(plan->d_scale_diag, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, st));
+    if (!sn.empty()) HIPCHK(hipMemcpyAsync(plan->d_scale_dense, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, st));
+    const unsigned nb = (unsigned)(plan->dd.size() + plan->dn.size());
+    DISPATCH_T(plan, hipLaunchKernelGGL(init_factors_kernel<T>, dim3(nb), dim3(256), 0, st, plan->d_dd, (int)plan->dd.size(),
+                                        plan->d_dn, (int)plan->dn.size(), plan->d_scale_diag, plan->d_scale_dense, plan->state));
+    HIPCHK(hipGetLastError());
+    plan->p_valid = false;
+    return PSGDK_OK;
+}
+
+int psgdk_state_changed(psgdk_plan* plan, void* stream) {
+    if (!plan) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!plan->dn.empty()) {
+        const unsigned nb = (unsigned)(plan->max_dp / 64);
+        DISPATCH_T(plan, hipLaunchKernelGGL(transpose_q_kernel<T>, dim3(nb, nb, (unsigned)plan->dn.size()), dim3(256), 0, st,
+                                            plan->d_dn, plan->state));
+        HIPCHK(hipGetLastError());
+    }
+    plan->p_valid = false;
+    return PSGDK_OK;
+}
+
+int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
+                     int param_dtype, float coupled_wd, float beta, int keep_grad, void* stream) {
+    if (!plan || !grads) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    if ((grad_dtype != PSGDK_BF16 && grad_dtype != PSGDK_F32) || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (coupled_wd != 0.f && !params) return PSGDK_ERR_INVALID;
+    if (!(beta >= 0.f && beta < 1.f)) return PSGDK_ERR_INVALID;
+    for (int t = 0; t < plan->n_tensors; ++t) if (!grads[t] || (coupled_wd != 0.f && !params[t])) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(plan->d_ptr_a, grads, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+    if (coupled_wd != 0.f) HIPCHK(hipMemcpyAsync(plan->d_ptr_b, params, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+    const int keep = (keep_grad || !plan->use_momentum) ? 1 : 0;
+    DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
+                                        plan->d_tiles_all, (const void* const*)plan->d_ptr_a, (const void* const*)plan->d_ptr_b,
+                                        plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+static int ensure_P(psgdk_plan* plan, hipStream_t st) {
+    if (!plan->p_valid) {
+        launch_stage(plan, plan->g_P, st);
+        HIPCHK(hipGetLastError());
+        plan->p_valid = true;
+    }
+    return PSGDK_OK;
+}
+
+int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                                   const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                                   const uint8_t* balance_mask, void* stream) {
+    if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+    if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
+    if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || !noise->skh_noise)))) return PSGDK_ERR_INVALID;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned F = (unsigned)P->dn.size();
+    int rc;
+    if (noise) {
+        HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+        if (F) {
+            std::vector<const void*> a(F), b(F);
+            for (unsigned f = 0; f < F; ++f) {
+                const int slot = P->dn[f].tensor * 2 + P->dense_dim[f];
+                a[f] = noise->spd_noise[slot]; b[f] = noise->skh_noise[slot];
+                if (!a[f] || !b[f]) return PSGDK_ERR_INVALID;
+            }
+            HIPCHK(hipMemcpyAsync(P->d_noise_spd, a.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(P->d_noise_skh, b.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
+        }
+    }
+    const void* const* ng = noise ? (const void* const*)P->d_noise_g : nullptr;
+    const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
+    const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
+
+    HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    // damped input X (psgd.py:402-403)
+    DISPATCH_T(P, hipLaunchKernelGGL(make_x_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
+                                     P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
+    // Pg = (kron Q^T Q) X and the mode Grams (psgd.py:403-405)
+    if ((rc = ensure_P(P, st))) return rc;
+    launch_stage(P, P->g_upd_a, st);
+    launch_stage(P, P->g_upd_b, st);
+    if (P->n_tiles_diag)
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
+                                         P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off)));
+    if (F) {
+        launch_stage(P, P->g_gram, st);
+        for (int f : P->split_dense) {
+            const DenseDesc& D = P->dn[f];
+            const GemmProblem& g = P->g_gram.probs[f];
+            const int nks = (g.K + g.kchunk - 1) / g.kchunk;
+            DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((D.dp + 255) / 256, D.dp), dim3(256), 0, st,
+                                             (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f));
+        }
+        const dim3 grows((unsigned)(P->max_dp / 64), F);
+        // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68)
+        DISPATCH_T(P, hipLaunchKernelGGL(spd_rowstats_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
+        for (int it = 0; it < 4; ++it)
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0, (it & 1) ? 0 : 1, it & 1));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL));
+        // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
+        launch_stage(P, P->g_qupd, st);
+        // procrustes_step2 (psgd.py:416 -> 101-124)
+        DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
+        for (int it = 0; it < 4; ++it)
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1, (it & 1) ? 0 : 1, it & 1));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL));
+        launch_stage(P, P->g_rq, st);
+        launch_stage(P, P->g_rrq, st);
+        const unsigned nb = (unsigned)std::min<size_t>(((size_t)P->max_dp * P->max_dp + 255) / 256, 1024);
+        DISPATCH_T(P, hipLaunchKernelGGL(procrustes_axpy_kernel<T>, dim3(nb, F), dim3(256), 0, st, P->d_dn, P->state, P->work, 0.125f));
+    }
+    // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
+    if (!P->dd.empty())
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(256), 0, st, P->d_dd, P->state,
+                                         P->work, lr, betaL));
+    // balancing (psgd.py:418-419)
+    if (balance_mask) {
+        std::vector<int> which;
+        for (int t = 0; t < P->n_tensors; ++t) if (balance_mask[t] && P->factors[t].size() > 1) which.push_back(t);
+        if (!which.empty()) {
+            HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, dim3((unsigned)which.size()), dim3(256), 0, st, P->d_td, P->d_dd,
+                                             P->d_dn, P->d_balance, P->state));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    P->p_valid = false;
+    return PSGDK_OK;
+}
+
+int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
+    if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
+    if ((rc = ensure_P(P, st))) return rc;
+    launch_stage(P, P->g_app_a[source], st);
+    launch_stage(P, P->g_app_b, st);
+    if (P->n_tiles_diag)
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
+                                         P->d_tiles_diag, P->state, P->work, 1, source == PSGDK_SRC_GRAD ? 1 : 0,
+                                         (float*)(P->work + P->hsumsq_off)));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, float lr, float decoupled_wd,
+                       float max_avg_amp, float max_elem_amp, void* stream) {
+    if (!plan || !params || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    if (!(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
+    for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(plan->d_ptr_b, params, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+    DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td, plan->d_tiles_all,
+                                        (void* const*)plan->d_ptr_b, param_dtype, plan->work,
+                                        (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,
+                            float max_elem_amp, void* stream) {
+    if (!plan || t < 0 || t >= plan->n_tensors || !out || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(plan->d_ptr_a, &out, sizeof(void*), hipMemcpyHostToDevice, st));
+    const unsigned b = plan->tile_begin[t], e = plan->tile_begin[t + 1];
+    DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(e - b), dim3(256), 0, st, plan->d_td, plan->d_tiles_all + b,
+                                        (void* const*)plan->d_ptr_a, out_dtype, plan->work,
+                                        (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
 int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
                       void* stream) {
     if (!out || n < 0 || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
@@ -36,29 +636,23 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     if (!A || !B || (!C && !Ct) || (M % 64) || (N % 64) || (K % 64) || M <= 0 || N <= 0 || K <= 0)
         return PSGDK_ERR_INVALID;
     if (dtype != PSGDK_BF16 && dtype != PSGDK_F32) return PSGDK_ERR_INVALID;
+    Stage s;
     GemmProblem P{};
     P.A = A; P.B = B; P.C = C; P.Ct = Ct;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldct = ldct;
     P.alpha = 1.0f; P.flags = symmetric ? GF_SYM : 0;
     if (symmetric) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
-    TileTableBuilder tb;
-    tb.add_problem(0, P);
-    std::vector<GemmTile> tiles = tb.finish();
-    GemmProblem* dP = nullptr; GemmTile* dT = nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipMalloc(&dP, sizeof(P)));
-    HIPCHK(hipMalloc(&dT, tiles.size() * sizeof(GemmTile)));
-    HIPCHK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dT, tiles.data(), tiles.size() * sizeof(GemmTile), hipMemcpyHostToDevice, s));
-    if (dtype == PSGDK_BF16)
-        hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, s, dP, dT);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3((unsigned)tiles.size()), dim3(256), 0, s, dP, dT);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(dP));
-    HIPCHK(hipFree(dT));
-    return PSGDK_OK;
+    s.probs.push_back(P);
+    int rc = finish_stage(s);
+    hipStream_t st = (hipStream_t)stream;
+    if (!rc) {
+        if (dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st);
+        if (hipGetLastError() != hipSuccess) rc = PSGDK_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) rc = PSGDK_ERR_HIP;
+    }
+    if (s.d_probs) (void)hipFree(s.d_probs);
+    if (s.d_tiles) (void)hipFree(s.d_tiles);
+    return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,171 @@
+"""KronEngine -- thin host object around one psgdk plan (include/psgdk.h).
+
+Owns the two arenas (as torch uint8 tensors, so that state is ordinary torch memory: checkpointable, visible to
+torch.distributed) and exposes Q / L / ema of every tensor as strided torch VIEWS of the state arena, in the layout
+the reference keeps in optimizer.state[p] (wrapped_as_torch_optimizer_for_ddp.py:129-137).  Every compute call goes
+to the HIP library; nothing here has a CPU or eager-torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+class KronEngine:
+    def __init__(self, shapes: Sequence[Sequence[int]], device, precond_dtype=torch.bfloat16, max_size=float("inf"),
+                 max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0):
+        """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124)."""
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, "KronEngine needs a ROCm device (cuda:N); there is no CPU fallback")
+        self.dtype = precond_dtype
+        self.code = L.dtype_code(precond_dtype)
+        self.shapes = [tuple(int(x) for x in s) for s in shapes]
+        self.n = len(self.shapes)
+        self.use_momentum = bool(use_momentum)
+        ndim = (C.c_int32 * self.n)(*[len(s) for s in self.shapes])
+        flat = [d for s in self.shapes for d in s]
+        dims = (C.c_int64 * max(len(flat), 1))(*flat)
+        self._plan = C.c_void_p()
+        L.check(self.lib.psgdk_plan_create(C.byref(self._plan), self.n, ndim, dims, float(max_size), float(max_skew),
+                                           self.code, int(self.use_momentum)), "plan_create")
+        sb, wb = C.c_size_t(), C.c_size_t()
+        L.check(self.lib.psgdk_plan_arena_bytes(self._plan, C.byref(sb), C.byref(wb)), "arena_bytes")
+        with torch.cuda.device(self.device):
+            self.state_arena = torch.zeros(sb.value, dtype=torch.uint8, device=self.device)
+            self.work_arena = torch.zeros(wb.value, dtype=torch.uint8, device=self.device)
+            L.check(self.lib.psgdk_plan_bind(self._plan, self.state_arena.data_ptr(), self.work_arena.data_ptr()), "bind")
+        self._build_views()
+        self._keep = []        # host pointer arrays kept alive until the next call
+        if init_scale is not None:
+            self.init_state(init_scale)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) is not None and self._plan.value:
+                self.lib.psgdk_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _typed(self, byte_off, numel, dtype):
+        esz = torch.empty(0, dtype=dtype).element_size()
+        return self.state_arena[byte_off:byte_off + numel * esz].view(dtype)
+
+    def _build_views(self):
+        self.kinds: List[List[int]] = []
+        self.Q: List[List[torch.Tensor]] = []
+        self.Lip: List[List[torch.Tensor]] = []
+        self.ema: List[Optional[torch.Tensor]] = []
+        for t in range(self.n):
+            nf = C.c_int()
+            L.check(self.lib.psgdk_plan_num_factors(self._plan, t, C.byref(nf)), "num_factors")
+            kinds, qs, ls = [], [], []
+            for i in range(nf.value):
+                kind, off, d, ld, loff = C.c_int(), C.c_size_t(), C.c_int64(), C.c_int64(), C.c_size_t()
+                L.check(self.lib.psgdk_plan_factor_view(self._plan, t, i, C.byref(kind), C.byref(off), C.byref(d),
+                                                        C.byref(ld), C.byref(loff)), "factor_view")
+                kinds.append(kind.value)
+                if kind.value == L.DENSE:
+                    base = self._typed(off.value, ld.value * ld.value, self.dtype)
+                    qs.append(torch.as_strided(base, (d.value, d.value), (ld.value, 1)))
+                elif kind.value == L.SCALAR:
+                    qs.append(self._typed(off.value, 1, self.dtype).view(()))
+                else:
+                    qs.append(self._typed(off.value, d.value, self.dtype))
+                ls.append(self._typed(loff.value, 1, torch.float32).view(()))
+            self.kinds.append(kinds)
+            self.Q.append(qs)
+            self.Lip.append(ls)
+            if self.use_momentum:
+                off, rows, cols, ld, tr = C.c_size_t(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+                L.check(self.lib.psgdk_plan_ema_view(self._plan, t, C.byref(off), C.byref(rows), C.byref(cols),
+                                                     C.byref(ld), C.byref(tr)), "ema_view")
+                r, c, l_ = rows.value, cols.value, ld.value
+                if tr.value:
+                    base = self._typed(off.value, (c - 1) * l_ + r, self.dtype)
+                    v = torch.as_strided(base, (r, c), (1, l_))
+                else:
+                    base = self._typed(off.value, (r - 1) * l_ + c, self.dtype)
+                    v = torch.as_strided(base, (r, c), (l_, 1))
+                self.ema.append(v.reshape(self.shapes[t]) if len(self.shapes[t]) != 2 else v)
+            else:
+                self.ema.append(None)
+
+    def QL(self, t):
+        """[[Q...], [L...]] of tensor t -- same structure as psgd.init_kron's first return value (psgd.py:259-260)."""
+        return [self.Q[t], self.Lip[t]]
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def init_state(self, scale: float):
+        L.check(self.lib.psgdk_init_state(self._plan, float(scale), self._stream()), "init_state")
+
+    def state_changed(self):
+        L.check(self.lib.psgdk_state_changed(self._plan, self._stream()), "state_changed")
+
+    def accumulate(self, grads: Sequence[torch.Tensor], params: Optional[Sequence[torch.Tensor]] = None,
+                   coupled_wd: float = 0.0, beta: float = 0.0, keep_grad: bool = False):
+        assert len(grads) == self.n
+        for g, s in zip(grads, self.shapes):
+            if not g.is_contiguous() or g.device != self.device:
+                raise L.PsgdkError(L.PSGDK_ERR_INVALID, "gradients must be contiguous tensors on the engine's device")
+        ga = L.ptr_array(grads)
+        pa = L.ptr_array(params) if params is not None else None
+        self._keep = [ga, pa, list(grads)]
+        pdt = L.dtype_code(params[0].dtype) if params is not None else L.F32
+        L.check(self.lib.psgdk_accumulate(self._plan, ga, L.dtype_code(grads[0].dtype), pa, pdt, float(coupled_wd),
+                                          float(beta), int(keep_grad), self._stream()), "accumulate")
+
+    def update_precond(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0,
+                       noise=None, balance_mask: Optional[Sequence[bool]] = None):
+        """noise: None (Philox) or (g_noise list[n], spd dict{(t,i): tensor}, skh dict{(t,i): tensor})."""
+        nz_ptr = None
+        keep = []
+        if noise is not None:
+            g_noise, spd, skh = noise
+            gl = [x.to(self.dtype).contiguous() for x in g_noise]
+            ga = L.ptr_array(gl)
+            sa = (C.c_void_p * (2 * self.n))()
+            ka = (C.c_void_p * (2 * self.n))()
+            for (t, i), x in spd.items():
+                x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * 2 + i] = x.data_ptr()
+            for (t, i), x in skh.items():
+                x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * 2 + i] = x.data_ptr()
+            nz = L.Noise(C.cast(ga, C.POINTER(C.c_void_p)), C.cast(sa, C.POINTER(C.c_void_p)),
+                         C.cast(ka, C.POINTER(C.c_void_p)))
+            keep += [gl, ga, sa, ka, nz]
+            nz_ptr = C.byref(nz)
+        bm = None
+        if balance_mask is not None:
+            bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
+        L.check(self.lib.psgdk_update_precond_q0p5eq1p5(self._plan, int(source), float(lr), float(betaL), float(damping),
+                                                        nz_ptr, int(seed), int(offset), bm, self._stream()),
+                "update_precond")
+        self._keep_noise = keep
+
+    def precond_grad(self, source: int):
+        L.check(self.lib.psgdk_precond_grad(self._plan, int(source), self._stream()), "precond_grad")
+
+    def apply_update(self, params: Sequence[torch.Tensor], lr: float, decoupled_wd: float, max_avg_amp: float,
+                     max_elem_amp: float):
+        pa = L.ptr_array(params)
+        self._keep_p = [pa, list(params)]
+        L.check(self.lib.psgdk_apply_update(self._plan, pa, L.dtype_code(params[0].dtype), float(lr), float(decoupled_wd),
+                                            float(max_avg_amp), float(max_elem_amp), self._stream()), "apply_update")
+
+    def read_precond_grad(self, t: int, out: Optional[torch.Tensor] = None, clip: bool = False, max_avg_amp: float = 2.0,
+                          max_elem_amp: float = 10.0) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.shapes[t], dtype=self.dtype, device=self.device)
+        L.check(self.lib.psgdk_read_precond_grad(self._plan, t, out.data_ptr(), L.dtype_code(out.dtype), int(clip),
+                                                 float(max_avg_amp), float(max_elem_amp), self._stream()), "read_h")
+        return out

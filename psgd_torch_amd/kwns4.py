@@ -1,0 +1,245 @@
+"""KWNS4 -- the torch.optim.Optimizer surface of the reference's wrapped_as_torch_optimizer_for_ddp.KWNS4
+(wrapped_as_torch_optimizer_for_ddp.py:4-176): same constructor arguments, defaults, assertions, param_groups /
+state layout and step() semantics (no closure), driven by the batched HIP engine instead of per-tensor ATen calls.
+
+What is different, on purpose:
+  * one grouped engine call per stage for ALL parameters of a group (the reference loops over parameters in Python
+    and syncs the host once per tensor at ..._ddp.py:154);
+  * randomness is a private counter-based stream (CPU generator for the Bernoulli gates, Philox (seed, step) on the
+    device), identical on every rank by construction -- the reference reaches the same lock-step by broadcasting and
+    swapping torch RNG states (..._ddp.py:88-104,172-176);
+  * `shard_state=True` (new; the reference only replicates): every rank owns a cost-balanced subset of
+    the parameters, preconditions only those, and the clipped preconditioned gradients are exchanged with ONE
+    all-gather (RCCL over xGMI); every rank then applies the identical parameter update.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import KronEngine
+from .sharding import lpt_partition, kron_step_cost
+
+
+class _Bucket:
+    """The parameters of one param_group that share (param dtype, grad dtype): one engine."""
+
+    def __init__(self):
+        self.params: List[torch.Tensor] = []
+        self.engine: Optional[KronEngine] = None
+        self.owned: List[int] = []          # indices into params this rank preconditions
+        self.step = 0
+        self.flat = None                     # sharded mode: gathered clipped h
+        self.segments = None
+
+
+class KWNS4(torch.optim.Optimizer):
+    def __init__(
+            self,
+            params,
+            whiten_grad=False,
+            preconditioner_max_size=float("inf"),
+            preconditioner_max_skew=1.0,
+            preconditioner_init_scale=1.0,
+            lr_params=2e-4,
+            lr_preconditioner=0.5,
+            betaL=0.9,
+            damping=1e-9,
+            momentum=0.9,
+            weight_decay=0.05,
+            decoupled_weight_decay=True,
+            grad_clip_max_amps=(2.0, 10.0),
+            preconditioner_update_probability=1.0,
+            preconditioner_dtype: Optional[torch.dtype] = torch.bfloat16,
+            update_preconditioner_first=True,
+            resync_every=1000_000,
+            *,
+            seed: int = 0,
+            shard_state: bool = False,
+            engine_factory=None,
+    ):
+        # the reference's argument checks, verbatim in meaning (..._ddp.py:45-62)
+        assert whiten_grad in (False, True)
+        assert preconditioner_max_size >= 0.0
+        assert preconditioner_max_skew >= 0.0
+        assert preconditioner_init_scale > 0.0
+        assert lr_params > 0.0
+        assert 0.0 < lr_preconditioner < 1.0
+        assert 0.0 <= betaL <= 1.0
+        assert damping >= 0.0
+        assert 0.0 <= momentum < 1.0
+        assert weight_decay >= 0.0
+        assert decoupled_weight_decay in (False, True)
+        assert grad_clip_max_amps[1] >= grad_clip_max_amps[0] >= 1.0
+        assert 0.0 < preconditioner_update_probability <= 1.0
+        assert preconditioner_dtype in (None, torch.bfloat16, torch.float32)
+        assert update_preconditioner_first in (False, True)
+        assert resync_every > 0
+        if not whiten_grad:
+            assert momentum > 0.0, "Cannot whiten momentum if momentum setting is zero."
+
+        defaults = {
+            "whiten_grad": whiten_grad,
+            "preconditioner_max_size": preconditioner_max_size,
+            "preconditioner_max_skew": preconditioner_max_skew,
+            "preconditioner_init_scale": preconditioner_init_scale,
+            "lr_params": lr_params,
+            "lr_preconditioner": lr_preconditioner,
+            "betaL": betaL,
+            "damping": damping,
+            "momentum": momentum,
+            "weight_decay": weight_decay,
+            "decoupled_weight_decay": decoupled_weight_decay,
+            "grad_clip_max_amps": grad_clip_max_amps,
+            "preconditioner_update_probability": preconditioner_update_probability,
+            "preconditioner_dtype": preconditioner_dtype,
+            "update_preconditioner_first": update_preconditioner_first,
+            "resync_every": resync_every,
+        }
+        super().__init__(params, defaults)
+
+        self.dQ = "Q0.5EQ1.5"
+        self.is_distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size() if self.is_distributed else 1
+        self.rank = torch.distributed.get_rank() if self.is_distributed else 0
+        self.shard_state = bool(shard_state) and self.world > 1
+        self._seed = int(seed)
+        self._gate_gen = torch.Generator().manual_seed(self._seed)      # same stream on every rank
+        self._buckets: Dict[tuple, _Bucket] = {}
+        self._engine_factory = engine_factory or KronEngine
+        self._global_step = 0
+        self._replay = None
+
+    # hook for tests that replay the reference's recorded draws
+    def _uniform(self) -> float:
+        return float(torch.rand([], generator=self._gate_gen))
+
+    def _update_draws(self, b, plist):
+        """The host-side draws of one batched update call: the per-tensor 1% balancing gates of psgd.py:418 (drawn for
+        ALL tensors on every rank so that the gate stream stays identical across ranks); device noise is Philox unless
+        a test installed `_replay` to feed the reference's recorded draws."""
+        if self._replay is not None:
+            return self._replay(b, plist)
+        u = [self._uniform() for _ in plist]
+        return dict(noise=None, balance_mask=[u[i] < 0.01 for i in b.owned])
+
+    # --------------------------------------------------------------------------------------------------------------
+    def _bucket_for(self, gi: int, group, plist: List[torch.Tensor]) -> _Bucket:
+        key = (gi, plist[0].dtype, plist[0].grad.dtype, plist[0].device)
+        b = self._buckets.get(key)
+        if b is not None:
+            if [id(p) for p in b.params] != [id(p) for p in plist]:
+                raise RuntimeError("KWNS4 (HIP engine): the set of parameters with gradients changed between steps; "
+                                   "per-step parameter skipping (..._ddp.py:114-115) is not built into the batched engine yet")
+            return b
+        b = _Bucket()
+        b.params = list(plist)
+        pd = group["preconditioner_dtype"] or plist[0].grad.dtype
+        shapes = [tuple(p.grad.squeeze().shape) for p in plist]                      # ..._ddp.py:124
+        if self.shard_state:
+            costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
+            owner = lpt_partition(costs, self.world)
+            b.owner = owner
+            b.owned = [i for i, o in enumerate(owner) if o == self.rank]
+        else:
+            b.owner = [self.rank] * len(plist)
+            b.owned = list(range(len(plist)))
+        b.shapes = shapes
+        if b.owned:
+            b.engine = self._engine_factory([shapes[i] for i in b.owned], plist[0].device, precond_dtype=pd,
+                                            max_size=group["preconditioner_max_size"],
+                                            max_skew=group["preconditioner_max_skew"],
+                                            use_momentum=group["momentum"] > 0.0,
+                                            init_scale=group["preconditioner_init_scale"])   # ..._ddp.py:131-137
+            for k, i in enumerate(b.owned):
+                st = self.state[plist[i]]
+                st["QL"] = b.engine.QL(k)
+                st["exprs"] = (b.engine, k)
+                st["ema"] = b.engine.ema[k]
+        for p in plist:
+            self.state[p]["step"] = 0
+        if self.shard_state:
+            # flat exchange buffer: equal-size (padded) segment per rank, in owner order
+            numels = [math.prod(s) if len(s) else 1 for s in shapes]
+            per_rank = [sum(numels[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
+            seg = max(per_rank + [1])
+            b.seg = seg
+            b.flat = torch.zeros(self.world * seg, dtype=pd, device=plist[0].device)
+            offs = [r * seg for r in range(self.world)]
+            b.h_views = []
+            for i, s in enumerate(shapes):
+                r = owner[i]
+                b.h_views.append(b.flat[offs[r]:offs[r] + numels[i]].view(s))
+                offs[r] += numels[i]
+        self._buckets[key] = b
+        return b
+
+    @torch.no_grad()
+    def step(self):
+        for gi, group in enumerate(self.param_groups):
+            momentum = group["momentum"]
+            max_avg_amp, max_element_amp = group["grad_clip_max_amps"]
+            if self._uniform() < group["preconditioner_update_probability"]:          # ..._ddp.py:109-110
+                updateP_first, updateP_last = group["update_preconditioner_first"], not group["update_preconditioner_first"]
+            else:
+                updateP_first, updateP_last = False, False
+            with_grad = [p for p in group["params"] if p.grad is not None]            # ..._ddp.py:113-115
+            if not with_grad:
+                continue
+            by_dtype: Dict[tuple, List[torch.Tensor]] = {}
+            for p in with_grad:
+                by_dtype.setdefault((p.dtype, p.grad.dtype, p.device), []).append(p)
+            for plist in by_dtype.values():
+                self._step_bucket(gi, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
+        self._global_step += 1
+
+    def _step_bucket(self, gi, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
+        b = self._bucket_for(gi, group, plist)
+        wd, lr = group["weight_decay"], group["lr_params"]
+        decoupled = group["decoupled_weight_decay"]
+        t = b.step
+        beta = min(t / (t + 1), momentum) if momentum > 0.0 else 0.0                  # ..._ddp.py:139-142
+        src_w = L.SRC_GRAD if group["whiten_grad"] else L.SRC_EMA                     # ..._ddp.py:145
+        src_p = L.SRC_GRAD if momentum == 0.0 else L.SRC_EMA                          # ..._ddp.py:150
+        eng = b.engine
+        if eng is not None:
+            own_p = [plist[i] for i in b.owned]
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in own_p]
+            coupled = wd if (wd > 0.0 and not decoupled) else 0.0
+            eng.accumulate(grads, params=own_p if coupled else None, coupled_wd=coupled, beta=beta,
+                           keep_grad=bool(group["whiten_grad"]) or momentum == 0.0)
+            if updateP_first:
+                eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
+                                   offset=2 * t, **self._update_draws(b, plist))
+            eng.precond_grad(src_p)
+            if not self.shard_state:
+                eng.apply_update(own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
+            else:
+                for k, i in enumerate(b.owned):
+                    eng.read_precond_grad(k, out=b.h_views[i], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
+            if updateP_last:
+                eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
+                                   offset=2 * t + 1, **self._update_draws(b, plist))
+        else:
+            if updateP_first or updateP_last:
+                [self._uniform() for _ in plist]          # keep the gate stream in lock-step with the owning ranks
+        if self.shard_state:
+            # ONE exchange step: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner is)
+            mine = b.flat[self.rank * b.seg:(self.rank + 1) * b.seg]
+            torch.distributed.all_gather_into_tensor(b.flat, mine.clone())
+            if wd > 0.0 and decoupled:
+                torch._foreach_mul_(plist, 1.0 - wd * lr)                             # ..._ddp.py:120
+            hs = [h.to(p.dtype).view_as(p) for h, p in zip(b.h_views, plist)]
+            torch._foreach_add_(plist, hs, alpha=-lr)                                 # ..._ddp.py:157
+        b.step += 1
+        for p in plist:
+            self.state[p]["step"] += 1
+        # ..._ddp.py:163-170: periodic resync of replicated state from rank 0 (drift from non-deterministic atomics)
+        if self.is_distributed and not self.shard_state and (b.step % group["resync_every"] == 0):
+            for p in plist:
+                torch.distributed.broadcast(p, src=0)
+            if eng is not None:
+                torch.distributed.broadcast(eng.state_arena, src=0)
