@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- PSGD-Kron step() throughput on GPT-2-small parameter shapes (BASELINE.json's metric and config).
+
+A "step" is ONE full KWNS4.step() over all 148 parameter tensors of GPT-2-small (124,475,904 params): coupled work
+of wrapped_as_torch_optimizer_for_ddp.py:98-176 -- momentum EMA, preconditioner update (probability 1) with the
+Q0.5EQ1.5 geometry, preconditioning, clipping, parameter update -- with bf16 preconditioner state, fp32 parameters and
+synthetic fp32 gradients already resident in HBM.  N > 1: preconditioner state is sharded per parameter across the
+ranks (shard_state=True) and the clipped preconditioned gradients are exchanged with one all-gather; total work is
+fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
+  roofline     -- for the dominant kernel (the grouped NT MFMA GEMM): algorithmic FLOPs of the GEMM launches of a step
+                  (SURVEY 8d model, minus the subspace-iteration term which runs in another kernel) / their launch time
+                  measured live with hipEvents on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def gpt2_shapes(n_layer=12, n_embd=768, vocab=50304, block=1024):
+    """misc/gpt2.py: GPTConfig defaults (gpt2.py:215-227), tied wte/lm_head (gpt2.py:252-254)."""
+    s = [(vocab, n_embd), (block, n_embd)]
+    for _ in range(n_layer):
+        s += [(n_embd,), (n_embd,), (3 * n_embd, n_embd), (3 * n_embd,), (n_embd, n_embd), (n_embd,),
+              (n_embd,), (n_embd,), (4 * n_embd, n_embd), (4 * n_embd,), (n_embd, 4 * n_embd), (n_embd,)]
+    s += [(n_embd,), (n_embd,)]
+    return s
+
+
+def flop_model(shapes, max_skew=1.0):
+    """SURVEY 8d.  Returns (step FLOPs, FLOPs that run in the grouped GEMM kernel)."""
+    step = gemm = 0.0
+    for shp in shapes:
+        N = math.prod(shp)
+        for d in shp:
+            if d <= 1 or d * d > max_skew * N:
+                continue
+            ap = min(4.0 * N * d, 2.0 * d ** 3 + 2.0 * N * d)
+            step += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + 512.0 * d ** 2
+            gemm += 2 * ap + 2.0 * N * d + 6.0 * d ** 3
+    return step, gemm
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU oracle (oracle/psgd_oracle.py, a port of the reference path) on ONE GPT-2-small transformer block
+    (12 tensors, 7,087,872 params), bf16 preconditioner, same hyper-parameters; bounded to ~seconds_budget."""
+    from oracle import psgd_oracle as orc
+    shapes = gpt2_shapes()[2:14]
+    gen = torch.Generator().manual_seed(0)
+    params = [0.02 * torch.randn(*s, generator=gen) for s in shapes]
+    opt = orc.KWNS4Oracle(params, seed=0)
+    nparam = sum(p.numel() for p in params)
+    times = []
+    t_all = time.time()
+    for it in range(50):
+        grads = [0.01 * torch.randn(*s, generator=gen) for s in shapes]
+        t0 = time.time()
+        opt.step(grads)
+        times.append(time.time() - t0)
+        if it >= 2 and time.time() - t_all > seconds_budget:
+            break
+    steady = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": nparam / steady / 1e9, "unit": "Gparam/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of 12 GPT-2-small blocks (12 tensors, {nparam} params), bf16 preconditioner, "
+                      f"median of {len(times) - 1} steps, {steady * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP engine)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = world > 1
+    if dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+
+    import psgd_torch_amd
+    shapes = gpt2_shapes()
+    nparam = sum(math.prod(s) for s in shapes)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    params = [torch.nn.Parameter(0.02 * torch.randn(*s, device=dev, generator=gen)) for s in shapes]
+    pd = torch.float32 if args.fp32 else torch.bfloat16
+    opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=pd, shard_state=dist)   # reference defaults otherwise
+    # synthetic gradient streams resident in HBM: a few distinct draws, cycled
+    n_sets = 2
+    grad_sets = [[0.01 * torch.randn(*s, device=dev, generator=gen) for s in shapes] for _ in range(n_sets)]
+
+    def one_step(i):
+        gs = grad_sets[i % n_sets]
+        for p, g in zip(params, gs):
+            p.grad = g
+        opt.step()
+
+    for i in range(args.warmup):
+        one_step(i)
+    engines = [b.engine for b in opt._buckets.values() if b.engine is not None]
+    for e in engines:
+        e.profile_read(reset=True)
+        e.profile_enable(True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_launches = 0.0, 0
+    for e in engines:
+        ms, n = e.profile_read(reset=True)
+        gemm_ms += ms
+        gemm_launches += n
+        e.profile_enable(False)
+    if dist:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    step_flops, gemm_flops = flop_model(shapes)
+    out = {
+        "metric": "psgd_kron_step_throughput",
+        "value": nparam / (dt / args.steps) / 1e9,
+        "unit": "Gparam/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "fp32" if args.fp32 else "bf16",
+        "data": "synthetic",
+        "config": {"workload": "GPT-2-small parameter shapes (misc/gpt2.py GPTConfig defaults): 148 tensors, "
+                               f"{nparam} params, 62 dense 768x768 Kron factors; KWNS4 defaults "
+                               "(momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
+                   "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
+                   "parallelism": "single GPU" if world == 1 else f"per-parameter state sharding x{world} + all-gather",
+                   "step_gflop_model": step_flops / 1e9},
+    }
+    if world == 1 and gemm_launches:
+        launches_per_step = gemm_launches / args.steps
+        avg_launch_s = gemm_ms / 1e3 / gemm_launches
+        achieved = (gemm_flops / launches_per_step) / avg_launch_s / 1e12
+        peak = 157.3 if args.fp32 else 2500.0
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16>" if not args.fp32 else "gemm_nt_kernel<float>",
+                           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                           "traffic": None, "launches_per_step": launches_per_step,
+                           "avg_launch_us": avg_launch_s * 1e6,
+                           "algorithmic_gflop_per_launch": gemm_flops / launches_per_step / 1e9,
+                           "gemm_ms_per_step": gemm_ms / args.steps,
+                           "whole_step_frac_of_peak": step_flops / (dt / args.steps) / 1e12 / peak}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,12 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
 int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
                       void* stream);
 
+/* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): when enabled, every gemm_nt launch is
+ * bracketed by hipEvents on the launch stream; psgdk_profile_read synchronises those events and returns the summed
+ * launch time (ms) and the launch count since the last reset. */
+int psgdk_profile_enable(psgdk_plan* plan, int enable);
+int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset);
+
 /* ---- kernel-level test hooks (used by tests/ and bench.py only) ------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T on padded row-major operands (all dims multiples of 64), same kernel the engine uses. */
 int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,

@@ -51,11 +51,16 @@ struct psgdk_plan {
     bool p_valid = false;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b;
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
+    // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t prof_used = 0;
 
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance);
+        for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b}) {
             fr(s->d_probs); fr(s->d_tiles);
         }
@@ -87,8 +92,19 @@ template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (s.n_tiles) hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
 }
-void launch_stage(const psgdk_plan* p, const Stage& s, hipStream_t st) {
+void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
+    if (!s.n_tiles) return;
+    const bool prof = p->prof;
+    if (prof) {
+        if (p->prof_used == p->prof_ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            p->prof_ev.emplace_back(a, b);
+        }
+        (void)hipEventRecord(p->prof_ev[p->prof_used].first, st);
+    }
     if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st);
+    if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used++].second, st);
 }
 
 #define DISPATCH_T(plan, CALL)                         \
@@ -616,6 +632,26 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
                                         (void* const*)plan->d_ptr_a, out_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp));
     HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_profile_enable(psgdk_plan* plan, int enable) {
+    if (!plan) return PSGDK_ERR_INVALID;
+    plan->prof = enable != 0;
+    return PSGDK_OK;
+}
+
+int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset) {
+    if (!plan || !gemm_ms || !gemm_launches) return PSGDK_ERR_INVALID;
+    double tot = 0.0;
+    for (size_t i = 0; i < plan->prof_used; ++i) {
+        HIPCHK(hipEventSynchronize(plan->prof_ev[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, plan->prof_ev[i].first, plan->prof_ev[i].second));
+        tot += ms;
+    }
+    *gemm_ms = tot; *gemm_launches = (int64_t)plan->prof_used;
+    if (reset) plan->prof_used = 0;
     return PSGDK_OK;
 }
 

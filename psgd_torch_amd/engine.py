@@ -169,3 +169,12 @@ class KronEngine:
         L.check(self.lib.psgdk_read_precond_grad(self._plan, t, out.data_ptr(), L.dtype_code(out.dtype), int(clip),
                                                  float(max_avg_amp), float(max_elem_amp), self._stream()), "read_h")
         return out
+
+    # live profiling of the grouped-GEMM launches (bench.py)
+    def profile_enable(self, on: bool = True):
+        L.check(self.lib.psgdk_profile_enable(self._plan, int(on)), "profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(self.lib.psgdk_profile_read(self._plan, C.byref(ms), C.byref(n), int(reset)), "profile_read")
+        return ms.value, n.value
