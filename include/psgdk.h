@@ -60,6 +60,11 @@ int psgdk_last_hip_error(void);
 int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, const int64_t* dims, double max_size,
                       double max_skew, int precond_dtype, int use_momentum);
 int psgdk_plan_destroy(psgdk_plan* plan);
+/* Optional, before psgdk_plan_bind: GLOBAL ids (< 2^28) of the plan's tensors for the Philox noise streams, so that a
+ * rank owning a subset of an optimizer's tensors draws exactly what a single GPU owning all of them would (default:
+ * the tensor's index in the plan).  New relative to the reference, which keeps replicas in lock-step by broadcasting
+ * torch RNG state (wrapped_as_torch_optimizer_for_ddp.py:88-104). */
+int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
 int psgdk_plan_arena_bytes(const psgdk_plan* plan, size_t* state_bytes, size_t* work_bytes);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "psgdk_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                     C.c_double, C.c_double, C.c_int, C.c_int]),
     "psgdk_plan_destroy": (C.c_int, [C.c_void_p]),
+    "psgdk_plan_set_stream_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "psgdk_plan_arena_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "psgdk_plan_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "psgdk_plan_num_factors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

@@ -46,7 +46,7 @@ struct psgdk_plan {
     void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
-    int* d_balance = nullptr;
+    int* d_balance = nullptr; float* d_balnorm = nullptr;
     int max_dp = 0;
     bool p_valid = false;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b;
@@ -59,7 +59,7 @@ struct psgdk_plan {
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
-        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance);
+        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b}) {
             fr(s->d_probs); fr(s->d_tiles);
@@ -180,6 +180,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
             fr.push_back(FactorRef{d0 ? PSGDK_DENSE : PSGDK_DIAG, -1});
             fr.push_back(FactorRef{d1 ? PSGDK_DENSE : PSGDK_DIAG, -1});
         }
+        D.stream_id = (unsigned)t;
         P->td.push_back(D);
         P->factors.push_back(fr);
         P->order.push_back(nd == 0 ? 1 : nd);
@@ -201,6 +202,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
                 F.c = (float)((double)D.numel / (double)len);
                 fr[i].idx = (int)P->dn.size();
                 (is_row ? D.row_dense : D.col_dense) = fr[i].idx;
+                F.stream_id = 0x40000000u + ((unsigned)t * 2u + (unsigned)i) * 2u;
                 P->dn.push_back(F);
                 P->dense_dim.push_back((int)i);
                 P->max_dp = std::max(P->max_dp, F.dp);
@@ -261,6 +263,18 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     }
     P->work_bytes = align256(wo);
     *out = P.release();
+    return PSGDK_OK;
+}
+
+int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
+    if (!plan || !ids) return PSGDK_ERR_INVALID;
+    if (plan->state) return PSGDK_ERR_STATE;      // descriptors are uploaded at bind time
+    for (int t = 0; t < plan->n_tensors; ++t) {
+        if (ids[t] >= 0x10000000u) return PSGDK_ERR_INVALID;
+        plan->td[t].stream_id = ids[t];
+    }
+    for (size_t f = 0; f < plan->dn.size(); ++f)
+        plan->dn[f].stream_id = 0x40000000u + (ids[plan->dn[f].tensor] * 2u + (unsigned)plan->dense_dim[f]) * 2u;
     return PSGDK_OK;
 }
 
@@ -354,6 +368,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if ((rc = alloc_ptrs(&P->d_noise_skh, P->dn.size()))) return rc;
     if (P->d_balance) { (void)hipFree(P->d_balance); P->d_balance = nullptr; }
     HIPCHK(hipMalloc((void**)&P->d_balance, P->n_tensors * sizeof(int)));
+    if (P->d_balnorm) { (void)hipFree(P->d_balnorm); P->d_balnorm = nullptr; }
+    HIPCHK(hipMalloc((void**)&P->d_balnorm, 2 * P->n_tensors * sizeof(float)));
     if (P->d_scale_diag) { (void)hipFree(P->d_scale_diag); P->d_scale_diag = nullptr; }
     if (P->d_scale_dense) { (void)hipFree(P->d_scale_dense); P->d_scale_dense = nullptr; }
     HIPCHK(hipMalloc((void**)&P->d_scale_diag, std::max<size_t>(P->dd.size(), 1) * 4));
@@ -570,7 +586,7 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     }
     // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
     if (!P->dd.empty())
-        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(256), 0, st, P->d_dd, P->state,
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
                                          P->work, lr, betaL));
     // balancing (psgd.py:418-419)
     if (balance_mask) {
@@ -578,8 +594,11 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         for (int t = 0; t < P->n_tensors; ++t) if (balance_mask[t] && P->factors[t].size() > 1) which.push_back(t);
         if (!which.empty()) {
             HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, dim3((unsigned)which.size()), dim3(256), 0, st, P->d_td, P->d_dd,
-                                             P->d_dn, P->d_balance, P->state));
+            HIPCHK(hipMemsetAsync(P->d_balnorm, 0, 2 * which.size() * sizeof(float), st));
+            const dim3 bg(64, (unsigned)(2 * which.size()));
+            for (int phase = 0; phase < 2; ++phase)
+                DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, bg, dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
+                                                 P->d_balance, P->state, P->d_balnorm, phase));
         }
     }
     HIPCHK(hipGetLastError());

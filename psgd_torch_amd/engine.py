@@ -17,8 +17,10 @@ from . import _lib as L
 
 class KronEngine:
     def __init__(self, shapes: Sequence[Sequence[int]], device, precond_dtype=torch.bfloat16, max_size=float("inf"),
-                 max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0):
-        """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124)."""
+                 max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0,
+                 tensor_ids: Optional[Sequence[int]] = None):
+        """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124).
+        tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices)."""
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -34,6 +36,10 @@ class KronEngine:
         self._plan = C.c_void_p()
         L.check(self.lib.psgdk_plan_create(C.byref(self._plan), self.n, ndim, dims, float(max_size), float(max_skew),
                                            self.code, int(self.use_momentum)), "plan_create")
+        if tensor_ids is not None:
+            assert len(tensor_ids) == self.n
+            ids = (C.c_uint32 * self.n)(*[int(i) for i in tensor_ids])
+            L.check(self.lib.psgdk_plan_set_stream_ids(self._plan, ids), "set_stream_ids")
         sb, wb = C.c_size_t(), C.c_size_t()
         L.check(self.lib.psgdk_plan_arena_bytes(self._plan, C.byref(sb), C.byref(wb)), "arena_bytes")
         with torch.cuda.device(self.device):

@@ -153,7 +153,8 @@ class KWNS4(torch.optim.Optimizer):
                                             max_size=group["preconditioner_max_size"],
                                             max_skew=group["preconditioner_max_skew"],
                                             use_momentum=group["momentum"] > 0.0,
-                                            init_scale=group["preconditioner_init_scale"])   # ..._ddp.py:131-137
+                                            init_scale=group["preconditioner_init_scale"],   # ..._ddp.py:131-137
+                                            tensor_ids=[(len(self._buckets) << 20) + i for i in b.owned])
             for k, i in enumerate(b.owned):
                 st = self.state[plist[i]]
                 st["QL"] = b.engine.QL(k)

@@ -1,0 +1,74 @@
+"""world_size-2 test of the N>1 (sharded) path on CPU with the gloo backend.
+
+The compute engine is the TEST-ONLY OracleEngine (tests/oracle_engine.py) injected through KWNS4's engine_factory,
+so this exercises exactly the host logic the GPU run uses: deterministic cost-balanced ownership, per-rank engines
+over owned tensors only, the single all-gather exchange of the clipped preconditioned gradients, identical parameter
+update on every rank, gate streams in lock-step.  The sharded result must equal the single-process result."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+SHAPES = [(24, 16), (16,), (16, 16), (1, 8, 1), (12, 20), (20,), (8, 8), ()]
+
+
+def _make(seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(0.5 * torch.randn(s, generator=g)) for s in SHAPES]
+
+
+def _run(params, steps, shard, **kw):
+    import psgd_torch_amd
+    from oracle_engine import OracleEngine
+    opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=shard,
+                               lr_params=1e-2, **kw)
+    g = torch.Generator().manual_seed(99)
+    for _ in range(steps):
+        for p in params:
+            p.grad = 0.3 * torch.randn(p.shape, generator=g)
+        opt.step()
+    return opt
+
+
+def _worker(rank, world, port, outdir, kw):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        params = _make(7)
+        opt = _run(params, 4, True, **kw)
+        owned = [len(b.owned) for b in opt._buckets.values()]
+        torch.save({"params": [p.data.clone() for p in params], "owned": owned}, os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(whiten_grad=True, update_preconditioner_first=False, weight_decay=0.0),
+                                dict(preconditioner_update_probability=0.5, momentum=0.5)])
+def test_sharded_equals_replicated(kw):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    ref_params = _make(7)
+    _run(ref_params, 4, False, **kw)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d, kw), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "r0.pt"))
+        r1 = torch.load(os.path.join(d, "r1.pt"))
+    assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
+    for a, b, c in zip(r0["params"], r1["params"], ref_params):
+        assert torch.equal(a, b), "ranks diverged"
+        assert torch.allclose(a, c.data, rtol=0, atol=0), "sharded result differs from the single-process result"
