@@ -142,6 +142,9 @@ int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches
  * C[M,N] = A[M,K] * B[N,K]^T on padded row-major operands (all dims multiples of 64), same kernel the engine uses. */
 int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,
                        int ldb, int ldc, int ldct, int symmetric, void* stream);
+/* times `iters` launches of a batch of identical dense problems (contiguous operands) with hipEvents: avg ms/launch */
+int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
+                          int symmetric, int iters, float* avg_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -425,7 +425,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         g.B = W + Fc.p_off; g.M = D.Rp; g.N = D.Cp; g.K = D.Cp; g.lda = D.Cp; g.ldb = Fc.dp; g.alpha = 1.f;
         if (D.kind == TK_M1) {
             g.row_scale = rs; g.flags = rs ? GF_SQ_ROWSCALE : 0;
-            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.pgt_off; u.ldct = D.Rp; u.row_sumsq = rsum;
+            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.pgt_off; u.ldct = D.Rp; u.row_sumsq = rsum; u.flags |= GF_TMAJOR;
             P->g_upd_a.probs.push_back(u);
             for (int src = 0; src < 2; ++src) {
                 GemmProblem a = g; a.A = src == PSGDK_SRC_GRAD ? (const void*)(W + D.gc_off) : (const void*)(S + D.ema_off);
@@ -434,11 +434,11 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             }
         } else {
             const DenseDesc& Fr = P->dn[D.row_dense];
-            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.tt_off; u.ldct = D.Rp;
+            GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.tt_off; u.ldct = D.Rp; u.flags |= GF_TMAJOR;
             P->g_upd_a.probs.push_back(u);
             for (int src = 0; src < 2; ++src) {
                 GemmProblem a = g; a.A = src == PSGDK_SRC_GRAD ? (const void*)(W + D.gc_off) : (const void*)(S + D.ema_off);
-                a.Ct = W + D.tt_off; a.ldct = D.Rp;
+                a.Ct = W + D.tt_off; a.ldct = D.Rp; a.flags |= GF_TMAJOR;
                 P->g_app_a[src].probs.push_back(a);
             }
             // second product: P_row * T, via T^T as the K-contiguous B operand
@@ -705,6 +705,43 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
         if (hipGetLastError() != hipSuccess) rc = PSGDK_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) rc = PSGDK_ERR_HIP;
     }
+    if (s.d_probs) (void)hipFree(s.d_probs);
+    if (s.d_tiles) (void)hipFree(s.d_tiles);
+    return rc;
+}
+
+int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
+                          int symmetric, int iters, float* avg_ms, void* stream) {
+    if (!A || !B || (!C && !Ct) || (M % 64) || (N % 64) || (K % 64) || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || iters <= 0 || !avg_ms)
+        return PSGDK_ERR_INVALID;
+    const size_t esz = dtype == PSGDK_BF16 ? 2 : 4;
+    Stage s;
+    for (int b = 0; b < batch; ++b) {
+        GemmProblem P{};
+        P.A = (const unsigned char*)A + (size_t)b * M * K * esz;
+        P.B = (const unsigned char*)B + (size_t)b * N * K * esz;
+        P.C = C ? (unsigned char*)C + (size_t)b * M * N * esz : nullptr;
+        P.Ct = Ct ? (unsigned char*)Ct + (size_t)b * M * N * esz : nullptr;
+        P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = K; P.ldc = N; P.ldct = M;
+        P.alpha = 1.0f; P.flags = (symmetric & 1 ? GF_SYM : 0) | (symmetric & ~1);
+        if (symmetric) { P.Ct = P.C; P.ldct = P.ldc; }
+        s.probs.push_back(P);
+    }
+    int rc = finish_stage(s);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    if (!rc) {
+        for (int i = 0; i < 3; ++i) { if (dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st); }
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters; ++i) { if (dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st); }
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = PSGDK_ERR_HIP;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_tiles) (void)hipFree(s.d_tiles);
     return rc;
