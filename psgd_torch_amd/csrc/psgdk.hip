@@ -236,6 +236,9 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->zero_off = wo;
     for (auto& F : P->dn) { F.sc_off = wo; wo += 64; }
     wo = align256(wo);
+    for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * PSGDK_SUBK * 4; }
+    wo = align256(wo);
+    for (auto& F : P->dn) { F.rowss_off = wo; wo += align256((size_t)F.dp * 4); }
     for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
     P->zero_bytes = wo - P->zero_off;
     P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
@@ -247,11 +250,10 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     }
     for (auto& F : P->dn) {
         const size_t mb = align256((size_t)F.dp * F.dp * esz);
-        size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off, &F.rrq_off, &F.rrqt_off};
+        size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off};
         for (size_t* o : offs) { *o = wo; wo += mb; }
         F.va_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
         F.vb_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
-        F.rowss_off = wo; wo += align256((size_t)F.dp * 4);
         // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
         const TensorDesc& D = P->td[F.tensor];
         const int K = F.is_row ? D.Cp : D.Rp;
@@ -395,6 +397,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         const int K = F.is_row ? D.Cp : D.Rp;
         g.A = Z; g.B = Z; g.C = W + F.t1_off; g.Ct = g.C;
         g.M = g.N = F.dp; g.K = K; g.lda = g.ldb = K; g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
+        // row sums of squares and max diagonal of term1 (psgd.py:59,61) straight from the epilogue
+        g.row_sumsq = (float*)(W + F.rowss_off); g.diag_max = sc + DS_NF;
         if (F.slab_off) {
             g.flags |= GF_SPLITK; g.kchunk = 3072; g.slab = (float*)(W + F.slab_off);
             P->split_dense.push_back((int)f);
@@ -410,8 +414,13 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         g = GemmProblem{};
         g.A = W + F.r_off; g.B = W + F.qtn_off; g.C = W + F.rq_off; g.Ct = W + F.rqt_off;
         g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.alpha_dev = sc + DS_S; g.trace = sc + DS_TR1;
+        // tr(R RQ) = -<R, RQ> (R antisymmetric): available from THIS product's epilogue, before R RQ is formed
+        g.dot_with = W + F.r_off; g.lddot = F.dp; g.dot_out = sc + DS_TR2;
         P->g_rq.probs.push_back(g);
-        g.B = W + F.rqt_off; g.C = W + F.rrq_off; g.Ct = W + F.rrqt_off; g.trace = sc + DS_TR2;
+        // Q = Q' + a (RQ + a/2 R RQ), straight into the state (Q and Qt); a from the device traces
+        g.dot_with = nullptr; g.dot_out = nullptr; g.trace = nullptr;
+        g.B = W + F.rqt_off; g.C = S + F.q_off; g.Ct = S + F.qt_off;
+        g.flags = GF_PROCR; g.X1 = W + F.qn_off; g.X2 = W + F.rq_off; g.ldq = F.dp; g.tr1_dev = sc + DS_TR1; g.tr2_dev = sc + DS_TR2;
         P->g_rrq.probs.push_back(g);
     }
     for (int t = 0; t < P->n_tensors; ++t) {
@@ -562,27 +571,24 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
             const GemmProblem& g = P->g_gram.probs[f];
             const int nks = (g.K + g.kchunk - 1) / g.kchunk;
             DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((D.dp + 255) / 256, D.dp), dim3(256), 0, st,
-                                             (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f));
+                                             (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, g.row_sumsq, g.diag_max, D.d));
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
-        // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68)
-        DISPATCH_T(P, hipLaunchKernelGGL(spd_rowstats_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-        for (int it = 0; it < 4; ++it)
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0, (it & 1) ? 0 : 1, it & 1));
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL));
+        // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
+        for (int p = 0; p < 4; ++p)
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0, p));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL));
         // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
         launch_stage(P, P->g_qupd, st);
-        // procrustes_step2 (psgd.py:416 -> 101-124)
+        // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
         DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
-        for (int it = 0; it < 4; ++it)
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1, (it & 1) ? 0 : 1, it & 1));
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
+        for (int p = 0; p < 4; ++p)
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1, p));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL));
         launch_stage(P, P->g_rq, st);
         launch_stage(P, P->g_rrq, st);
-        const unsigned nb = (unsigned)std::min<size_t>(((size_t)P->max_dp * P->max_dp + 255) / 256, 1024);
-        DISPATCH_T(P, hipLaunchKernelGGL(procrustes_axpy_kernel<T>, dim3(nb, F), dim3(256), 0, st, P->d_dn, P->state, P->work, 0.125f));
     }
     // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
     if (!P->dd.empty())
