@@ -49,21 +49,25 @@ struct psgdk_plan {
     int* d_balance = nullptr; float* d_balnorm = nullptr;
     int max_dp = 0;
     bool p_valid = false;
-    Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b;
+    Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
     // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     size_t prof_used = 0;
 
+    std::vector<Stage*> all_stages() {
+        std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
+        for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
+        return v;
+    }
+
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        for (Stage* s : {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b}) {
-            fr(s->d_probs); fr(s->d_tiles);
-        }
+        for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
     }
 };
 
@@ -236,7 +240,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->zero_off = wo;
     for (auto& F : P->dn) { F.sc_off = wo; wo += 64; }
     wo = align256(wo);
-    for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * PSGDK_SUBK * 4; }
+    for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * 64 * 4; }
     wo = align256(wo);
     for (auto& F : P->dn) { F.rowss_off = wo; wo += align256((size_t)F.dp * 4); }
     for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
@@ -252,8 +256,8 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
         const size_t mb = align256((size_t)F.dp * F.dp * esz);
         size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off};
         for (size_t* o : offs) { *o = wo; wo += mb; }
-        F.va_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
-        F.vb_off = wo; wo += align256((size_t)PSGDK_SUBK * F.dp * 4);
+        F.va_off = wo; wo += align256((size_t)64 * F.dp * esz);
+        F.vb_off = wo; wo += align256((size_t)64 * F.dp * esz);
         // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
         const TensorDesc& D = P->td[F.tensor];
         const int K = F.is_row ? D.Cp : D.Rp;
@@ -378,8 +382,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     HIPCHK(hipMalloc((void**)&P->d_scale_dense, std::max<size_t>(P->dn.size(), 1) * 4));
 
     // ---- grouped GEMM stages (absolute pointers, so built at bind time) ----
-    for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1], &P->g_app_b})
-        s->probs.clear();
+    for (Stage* s : P->all_stages()) s->probs.clear();
     P->split_dense.clear();
     float* hsumsq = (float*)(W + P->hsumsq_off);
     for (size_t f = 0; f < P->dn.size(); ++f) {
@@ -404,6 +407,19 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->split_dense.push_back((int)f);
         }
         P->g_gram.probs.push_back(g);
+        // subspace iteration of norm_lower_bound_spd (A = term1) and _skh (A = R): V <- V (A/nf), psgd.py:65-67
+        for (int chain = 0; chain < 2; ++chain)
+            for (int p = 0; p < 4; ++p) {
+                g = GemmProblem{};
+                float* vsq = (float*)(W + F.vsq_off) + (chain * 4 + p) * 64;
+                g.A = W + ((p & 1) ? F.vb_off : F.va_off); g.B = W + (chain ? F.r_off : F.t1_off);
+                g.C = W + ((p & 1) ? F.va_off : F.vb_off);
+                g.M = 64; g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = F.dp; g.alpha = 1.f;
+                g.alpha_dev = sc + (chain ? DS_INVNF_SKH : DS_INVNF_SPD);
+                g.row_sumsq = vsq;
+                if (p & 1) { g.row_scale = vsq - 64; g.flags = GF_RSQRT_ROWSCALE; }
+                P->g_nlb[chain][p].probs.push_back(g);
+            }
         // Q' = Q - mu (term1 Q - c Q)   (psgd.py:415)
         g = GemmProblem{};
         g.A = W + F.t1_off; g.B = S + F.qt_off; g.C = W + F.qn_off; g.Ct = W + F.qtn_off;
@@ -459,7 +475,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->g_app_b.probs.push_back(ab);
         }
     }
-    for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1], &P->g_app_b})
+    for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
     return PSGDK_OK;
 }
@@ -576,16 +592,14 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         const dim3 grows((unsigned)(P->max_dp / 64), F);
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-        for (int p = 0; p < 4; ++p)
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0, p));
+        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL));
         // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
         launch_stage(P, P->g_qupd, st);
         // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
         DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
-        for (int p = 0; p < 4; ++p)
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_mult_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1, p));
+        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL));
         launch_stage(P, P->g_rq, st);
         launch_stage(P, P->g_rrq, st);
