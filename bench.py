@@ -47,7 +47,7 @@ def flop_model(shapes, max_skew=1.0):
                 continue
             ap = min(4.0 * N * d, 2.0 * d ** 3 + 2.0 * N * d)
             step += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + 512.0 * d ** 2
-            gemm += 2 * ap + 2.0 * N * d + 6.0 * d ** 3
+            gemm += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + 512.0 * d ** 2    # the subspace iterations are GEMM problems too
     return step, gemm
 
 

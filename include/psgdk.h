@@ -91,8 +91,18 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream);
  * NULL when coupled_wd == 0).  beta = min(t/(t+1), momentum) is computed by the caller per ..._ddp.py:141.
  * Produces ema <- beta*ema + (1-beta)*cast(g + coupled_wd*p) (if the plan has momentum); keep_grad != 0 (forced when
  * the plan has no momentum) also keeps cast(g) for PSGDK_SRC_GRAD consumers (whiten_grad=True, ..._ddp.py:145). */
+struct psgdk_noise;
+/* Optional fusion hint: when the caller knows psgdk_update_precond_q0p5eq1p5 will follow with exactly these arguments,
+ * psgdk_accumulate also writes the update's damped input G + (damping + eps|G|) * noise (psgd.py:402-403) in the same
+ * pass; the update call then skips that stage.  NULL = no fusion (the update computes it itself). */
+typedef struct psgdk_damp {
+    int source;                     /* PSGDK_SRC_EMA | PSGDK_SRC_GRAD */
+    float damping;
+    const struct psgdk_noise* noise;   /* explicit g_noise (only that member is read here) or NULL for Philox */
+    uint64_t seed, offset;
+} psgdk_damp;
 int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
-                     int param_dtype, float coupled_wd, float beta, int keep_grad, void* stream);
+                     int param_dtype, float coupled_wd, float beta, int keep_grad, const psgdk_damp* damp, void* stream);
 
 /* explicit noise for parity testing (all device pointers, element type = precond dtype, logical layouts):
  *   g_noise[t]            : numel(t) values, the randn_like(G) of psgd.py:403

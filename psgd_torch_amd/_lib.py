@@ -23,6 +23,11 @@ class Noise(C.Structure):
                 ("skh_noise", C.POINTER(C.c_void_p))]
 
 
+class Damp(C.Structure):
+    _fields_ = [("source", C.c_int), ("damping", C.c_float), ("noise", C.POINTER(Noise)), ("seed", C.c_uint64),
+                ("offset", C.c_uint64)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/psgdk.h declares
@@ -44,7 +49,7 @@ SIGNATURES = {
     "psgdk_init_state": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "psgdk_state_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psgdk_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int,
-                                   C.c_float, C.c_float, C.c_int, C.c_void_p]),
+                                   C.c_float, C.c_float, C.c_int, C.POINTER(Damp), C.c_void_p]),
     "psgdk_update_precond_q0p5eq1p5": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                                  C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8),
                                                  C.c_void_p]),

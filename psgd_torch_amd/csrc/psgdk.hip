@@ -49,6 +49,7 @@ struct psgdk_plan {
     int* d_balance = nullptr; float* d_balnorm = nullptr;
     int max_dp = 0;
     bool p_valid = false;
+    bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
     // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
@@ -513,7 +514,7 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream) {
 }
 
 int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
-                     int param_dtype, float coupled_wd, float beta, int keep_grad, void* stream) {
+                     int param_dtype, float coupled_wd, float beta, int keep_grad, const psgdk_damp* damp, void* stream) {
     if (!plan || !grads) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
     if ((grad_dtype != PSGDK_BF16 && grad_dtype != PSGDK_F32) || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
@@ -524,10 +525,30 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     HIPCHK(hipMemcpyAsync(plan->d_ptr_a, grads, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
     if (coupled_wd != 0.f) HIPCHK(hipMemcpyAsync(plan->d_ptr_b, params, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
     const int keep = (keep_grad || !plan->use_momentum) ? 1 : 0;
+    // optional fusion of the update's damped input X (psgd.py:402-403) into this pass (saves one read of the source)
+    plan->x_valid = false;
+    const void* const* ng = nullptr;
+    int do_x = 0, x_from_grad = 0;
+    float damping = 0.f; uint64_t seed = 0, offset = 0;
+    if (damp) {
+        if ((damp->source != PSGDK_SRC_EMA && damp->source != PSGDK_SRC_GRAD) || !(damp->damping >= 0.f)) return PSGDK_ERR_INVALID;
+        if (damp->source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+        if (damp->noise) {
+            if (!damp->noise->g_noise) return PSGDK_ERR_INVALID;
+            HIPCHK(hipMemcpyAsync(plan->d_noise_g, damp->noise->g_noise, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+            ng = (const void* const*)plan->d_noise_g;
+        }
+        do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
+    }
     DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
                                         plan->d_tiles_all, (const void* const*)plan->d_ptr_a, (const void* const*)plan->d_ptr_b,
-                                        plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep));
+                                        plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
+                                        do_x, x_from_grad, damping, ng, seed, offset));
     HIPCHK(hipGetLastError());
+    if (damp) {
+        plan->x_valid = true; plan->x_source = damp->source; plan->x_damping = damp->damping;
+        plan->x_seed = damp->seed; plan->x_offset = damp->offset; plan->x_explicit = damp->noise != nullptr;
+    }
     return PSGDK_OK;
 }
 
@@ -570,9 +591,13 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
     HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
-    // damped input X (psgd.py:402-403)
-    DISPATCH_T(P, hipLaunchKernelGGL(make_x_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
-                                     P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
+    // damped input X (psgd.py:402-403), unless psgdk_accumulate already produced exactly this X
+    const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
+                         P->x_offset == offset && P->x_explicit == (noise != nullptr);
+    P->x_valid = false;
+    if (!x_ready)
+        DISPATCH_T(P, hipLaunchKernelGGL(make_x_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
+                                         P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
     // Pg = (kron Q^T Q) X and the mode Grams (psgd.py:403-405)
     if ((rc = ensure_P(P, st))) return rc;
     launch_stage(P, P->g_upd_a, st);

@@ -119,7 +119,9 @@ class KronEngine:
         L.check(self.lib.psgdk_state_changed(self._plan, self._stream()), "state_changed")
 
     def accumulate(self, grads: Sequence[torch.Tensor], params: Optional[Sequence[torch.Tensor]] = None,
-                   coupled_wd: float = 0.0, beta: float = 0.0, keep_grad: bool = False):
+                   coupled_wd: float = 0.0, beta: float = 0.0, keep_grad: bool = False, damp: Optional[dict] = None):
+        """damp = dict(source, damping, seed, offset): fuse the damped input of an update_precond call that will follow
+        with exactly these arguments (Philox noise only) into this pass."""
         assert len(grads) == self.n
         for g, s in zip(grads, self.shapes):
             if not g.is_contiguous() or g.device != self.device:
@@ -128,8 +130,13 @@ class KronEngine:
         pa = L.ptr_array(params) if params is not None else None
         self._keep = [ga, pa, list(grads)]
         pdt = L.dtype_code(params[0].dtype) if params is not None else L.F32
+        dp = None
+        if damp is not None:
+            d = L.Damp(int(damp["source"]), float(damp["damping"]), None, int(damp["seed"]), int(damp["offset"]))
+            self._keep.append(d)
+            dp = C.byref(d)
         L.check(self.lib.psgdk_accumulate(self._plan, ga, L.dtype_code(grads[0].dtype), pa, pdt, float(coupled_wd),
-                                          float(beta), int(keep_grad), self._stream()), "accumulate")
+                                          float(beta), int(keep_grad), dp, self._stream()), "accumulate")
 
     def update_precond(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0,
                        noise=None, balance_mask: Optional[Sequence[bool]] = None):

@@ -210,8 +210,12 @@ class KWNS4(torch.optim.Optimizer):
             own_p = [plist[i] for i in b.owned]
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in own_p]
             coupled = wd if (wd > 0.0 and not decoupled) else 0.0
+            damp = None
+            if (updateP_first or updateP_last) and self._replay is None:
+                # the update that follows in this step reads G + (damping + eps|G|) * noise: let the momentum pass write it
+                damp = dict(source=src_w, damping=group["damping"], seed=self._seed, offset=2 * t + (0 if updateP_first else 1))
             eng.accumulate(grads, params=own_p if coupled else None, coupled_wd=coupled, beta=beta,
-                           keep_grad=bool(group["whiten_grad"]) or momentum == 0.0)
+                           keep_grad=bool(group["whiten_grad"]) or momentum == 0.0, damp=damp)
             if updateP_first:
                 eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
                                    offset=2 * t, **self._update_draws(b, plist))

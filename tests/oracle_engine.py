@@ -34,7 +34,7 @@ class OracleEngine:
     def QL(self, k):
         return self.QLs[k]
 
-    def accumulate(self, grads, params=None, coupled_wd=0.0, beta=0.0, keep_grad=False):
+    def accumulate(self, grads, params=None, coupled_wd=0.0, beta=0.0, keep_grad=False, damp=None):
         for k, g in enumerate(grads):
             if coupled_wd:
                 g = g.add(params[k], alpha=coupled_wd)
