@@ -172,9 +172,17 @@ def main():
         avg_launch_s = gemm_ms / 1e3 / gemm_launches
         achieved = (gemm_flops / launches_per_step) / avg_launch_s / 1e12
         peak = 157.3 if args.fp32 else 2500.0
+        # HBM bytes per launch come from a separate rocprofv3 --pmc run (profiles/): counters cannot be read in-process
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if os.path.exists(tpath) and not args.fp32:
+            try:
+                traffic = json.load(open(tpath))["kernels"]["gemm_nt_kernelIt"]["hbm_bytes_per_launch_corrected"]
+            except Exception:
+                traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16>" if not args.fp32 else "gemm_nt_kernel<float>",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                           "traffic": None, "launches_per_step": launches_per_step,
+                           "traffic": traffic, "launches_per_step": launches_per_step,
                            "avg_launch_us": avg_launch_s * 1e6,
                            "algorithmic_gflop_per_launch": gemm_flops / launches_per_step / 1e9,
                            "gemm_ms_per_step": gemm_ms / args.steps,
