@@ -142,6 +142,24 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
 int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
                       void* stream);
 
+/* ===================================================================================================================
+ * LRA preconditioner Q = (I + U V^T) diag(d) on the concatenated parameter vector (psgd.py:987-1072).
+ * U, V: N x r row-major, d: N, element type = dtype (PSGDK_BF16 | PSGDK_F32), all caller-owned device memory;
+ * Luvd: 3 fp32 device scalars (Lu, Lv, Ld; psgd.py:1123).  r <= 16.
+ * =================================================================================================================== */
+typedef struct psgdk_lra psgdk_lra;
+int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype);
+int psgdk_lra_destroy(psgdk_lra* lra);
+int psgdk_lra_work_bytes(const psgdk_lra* lra, size_t* work_bytes);
+int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void* work);
+/* replaces psgd.update_precond_lra_whiten (psgd.py:1066-1072) -> update_precond_lra (psgd.py:994-1052), in place on
+ * U, V, d, Luvd.  g: the N-vector to whiten; v_noise: the randn_like(g) draw of psgd.py:1070 or NULL for Philox
+ * (seed, offset); update_u: the caller's rand([]) < 0.5 coin of psgd.py:1035 (nonzero = update U, else V). */
+int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                            float lr, float betaL, float damping, void* stream);
+/* replaces psgd.precond_grad_lra (psgd.py:1055-1063): out = Q^T Q g. */
+int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream);
+
 /* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): when enabled, every gemm_nt launch is
  * bracketed by hipEvents on the launch stream; psgdk_profile_read synchronises those events and returns the summed
  * launch time (ms) and the launch count since the last reset. */

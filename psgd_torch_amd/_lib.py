@@ -58,6 +58,13 @@ SIGNATURES = {
                                      C.c_float, C.c_void_p]),
     "psgdk_read_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_void_p]),
+    "psgdk_lra_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_int]),
+    "psgdk_lra_destroy": (C.c_int, [C.c_void_p]),
+    "psgdk_lra_work_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "psgdk_lra_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psgdk_lra_update_whiten": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_float,
+                                          C.c_float, C.c_float, C.c_void_p]),
+    "psgdk_lra_precond_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "psgdk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "psgdk_fill_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),

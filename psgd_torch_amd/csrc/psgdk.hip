@@ -7,6 +7,7 @@
 #include "descs.hiph"
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
+#include "kernels_lra.hiph"
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -790,6 +791,103 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_tiles) (void)hipFree(s.d_tiles);
     return rc;
+}
+
+}  // extern "C"
+
+// ===================================================================================================================
+// LRA preconditioner (psgd.py:987-1072)
+// ===================================================================================================================
+struct psgdk_lra {
+    int64_t N = 0; int r = 0; int dtype = 0; size_t esz = 4;
+    void* U = nullptr; void* V = nullptr; void* d = nullptr; float* Luvd = nullptr;
+    unsigned char* work = nullptr;
+    size_t sm_off = 0, v_off = 0, h_off = 0, qh_off = 0, iq_off = 0, diff_off = 0, y_off = 0, work_bytes = 0;
+};
+
+extern "C" {
+
+int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype) {
+    if (!out || N <= 0 || r < 0 || r > LRA_RMAX || (r > 0 && r >= N) || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    psgdk_lra* L = new psgdk_lra();
+    L->N = N; L->r = r; L->dtype = dtype; L->esz = dtype == PSGDK_BF16 ? 2 : 4;
+    size_t wo = 0;
+    L->sm_off = wo; wo += align256((size_t)LS_TOTAL * 4);
+    const size_t nb = align256((size_t)N * L->esz);
+    L->v_off = wo; wo += nb; L->h_off = wo; wo += nb; L->qh_off = wo; wo += nb; L->iq_off = wo; wo += nb;
+    L->diff_off = wo; wo += nb; L->y_off = wo; wo += nb;
+    L->work_bytes = wo;
+    *out = L;
+    return PSGDK_OK;
+}
+
+int psgdk_lra_destroy(psgdk_lra* lra) { delete lra; return PSGDK_OK; }
+
+int psgdk_lra_work_bytes(const psgdk_lra* lra, size_t* work_bytes) {
+    if (!lra || !work_bytes) return PSGDK_ERR_INVALID;
+    *work_bytes = lra->work_bytes;
+    return PSGDK_OK;
+}
+
+int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void* work) {
+    if (!lra || !d || !Luvd || !work || (lra->r > 0 && (!U || !V))) return PSGDK_ERR_INVALID;
+    lra->U = U; lra->V = V; lra->d = d; lra->Luvd = Luvd; lra->work = (unsigned char*)work;
+    return PSGDK_OK;
+}
+
+#define LRA_T(L, CALL) do { if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; CALL; } else { typedef float T; CALL; } } while (0)
+
+int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                            float lr, float betaL, float damping, void* stream) {
+    if (!lra || !g) return PSGDK_ERR_INVALID;
+    if (!lra->work) return PSGDK_ERR_STATE;
+    if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
+    psgdk_lra* L = lra;
+    hipStream_t st = (hipStream_t)stream;
+    float* sm = (float*)(L->work + L->sm_off);
+    const int64_t N = L->N; const int r = L->r;
+    const unsigned gb = (unsigned)std::min<int64_t>((N + LRA_ROWS - 1) / LRA_ROWS, 2048);
+    HIPCHK(hipMemsetAsync(sm, 0, (size_t)LS_TOTAL * 4, st));
+    LRA_T(L, {
+        T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
+        T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
+        T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
+        hipLaunchKernelGGL(lra_prep_kernel<T>, dim3(gb), dim3(256), 0, st, (const T*)g, (const T*)v_noise, v, h, N, damping, seed, offset);
+        if (r > 0) {
+            hipLaunchKernelGGL(lra_gram_kernel<T>, dim3(std::min<unsigned>(gb, 1024)), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm);
+            hipLaunchKernelGGL(lra_small1_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
+        }
+        hipLaunchKernelGGL(lra_rotate_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+        hipLaunchKernelGGL(lra_small2_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
+        hipLaunchKernelGGL(lra_pass3_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+                           (const T*)h, Qh, iq, N, r, sm);
+        hipLaunchKernelGGL(lra_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
+        hipLaunchKernelGGL(lra_pass4_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+                           (const T*)h, (const T*)Qh, (const T*)iq, diff, N, r, sm);
+        hipLaunchKernelGGL(lra_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
+        hipLaunchKernelGGL(lra_pass5_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+                           N, r, update_u ? 1 : 0, (const float*)sm);
+    });
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream) {
+    if (!lra || !g || !out) return PSGDK_ERR_INVALID;
+    if (!lra->work) return PSGDK_ERR_STATE;
+    psgdk_lra* L = lra;
+    hipStream_t st = (hipStream_t)stream;
+    float* sm = (float*)(L->work + L->sm_off);
+    const unsigned gb = (unsigned)std::min<int64_t>((L->N + LRA_ROWS - 1) / LRA_ROWS, 2048);
+    HIPCHK(hipMemsetAsync(sm + LS_VTX2, 0, 32 * 4, st));
+    LRA_T(L, {
+        T* y = (T*)(L->work + L->y_off);
+        for (int stage = 0; stage < 3; ++stage)
+            hipLaunchKernelGGL(lra_apply_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+                               (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
+    });
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
 }
 
 }  // extern "C"
