@@ -30,6 +30,7 @@ extern "C" {
 #endif
 
 #define PSGDK_VERSION 100
+#define PSGDK_MAX_DIMS 8      /* most dims (after squeeze) of one tensor */
 
 /* status codes */
 enum {
@@ -56,7 +57,8 @@ int psgdk_last_hip_error(void);
 /* ---- planning: replaces psgd.init_kron's structural half (psgd.py:161-263, dense/diag rule psgd.py:208) -----
  * n_tensors tensors; tensor t has ndim[t] dims (AFTER squeeze(), ..._ddp.py:124) listed consecutively in `dims`.
  * precond_dtype: PSGDK_BF16 | PSGDK_F32 (..._ddp.py:41,58).  use_momentum: allocate the EMA buffers (..._ddp.py:137).
- * Tensors with more than 26 dims -> PSGDK_ERR_INVALID (psgd.py:197-198); with > 2 dims -> PSGDK_ERR_UNSUPPORTED. */
+ * Tensors with more than 26 dims -> PSGDK_ERR_INVALID (psgd.py:197-198); with > PSGDK_MAX_DIMS -> PSGDK_ERR_UNSUPPORTED.
+ * Tensors with <= 2 dims take the grouped-GEMM path; 3..PSGDK_MAX_DIMS dims a generic mode-product path. */
 int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, const int64_t* dims, double max_size,
                       double max_skew, int precond_dtype, int use_momentum);
 int psgdk_plan_destroy(psgdk_plan* plan);
@@ -106,8 +108,8 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
 
 /* explicit noise for parity testing (all device pointers, element type = precond dtype, logical layouts):
  *   g_noise[t]            : numel(t) values, the randn_like(G) of psgd.py:403
- *   spd_noise[t*2+i]      : 32 x d_i values, the randn(32,d) of psgd.py:62 for dense factor i of tensor t
- *   skh_noise[t*2+i]      : 32 x d_i values, the randn(32,d) of psgd.py:87
+ *   spd_noise[t*PSGDK_MAX_DIMS+i] : 32 x d_i values, the randn(32,d) of psgd.py:62 for dense factor i of tensor t
+ *   skh_noise[t*PSGDK_MAX_DIMS+i] : 32 x d_i values, the randn(32,d) of psgd.py:87
  * A NULL psgdk_noise* selects the built-in Philox4x32-10 stream keyed by (seed, offset). */
 typedef struct psgdk_noise {
     const void* const* g_noise;

@@ -8,6 +8,7 @@
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
 #include "kernels_lra.hiph"
+#include "kernels_gen.hiph"
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -34,7 +35,10 @@ struct psgdk_plan {
     std::vector<DenseDesc> dn;
     std::vector<std::vector<FactorRef>> factors;    // per tensor, logical dim order
     std::vector<int> order;                          // number of factors per tensor (k of scale^(1/k))
-    std::vector<int> dense_dim;                      // per dense factor: logical dim index (0/1)
+    std::vector<int> dense_dim;                      // per dense factor: logical dim index
+    std::vector<GenDesc> gd;                         // tensors with > 2 dims
+    GenDesc* d_gd = nullptr;
+    std::vector<int> gram_prob;                      // per dense factor: its problem in g_gram, or -1 (N-D tensors)
     size_t state_bytes = 0, work_bytes = 0;
     size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0;
     unsigned char* state = nullptr;
@@ -67,7 +71,7 @@ struct psgdk_plan {
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
-        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm);
+        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
     }
@@ -118,6 +122,31 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
         if ((plan)->dtype == PSGDK_BF16) { typedef bf16_t T; CALL; } else { typedef float T; CALL; } \
     } while (0)
 
+// (kron_i F_i) applied mode by mode to an N-D tensor (psgd.py:251-252, exprP): F_i = P_i = Q_i^T Q_i (dense, from the
+// batched P stage) or diag(q_i^2).  src -> ping-pong buffers -> dst (dst may be one of the ping-pong buffers' owner h).
+// Returns the buffer holding the result when dst == nullptr.
+template <typename T>
+static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T* dst, float* sumsq, hipStream_t st) {
+    const int64_t numel = P->td[g.tensor].numel;
+    const T* cur = src;
+    int64_t A = 1;
+    for (int i = 0; i < g.ndim; ++i) {
+        const int s_ = g.dims[i];
+        const int64_t B = numel / (A * s_);
+        const bool last = (i == g.ndim - 1);
+        T* out = (last && dst) ? dst : (T*)(P->work + g.pp_off[i & 1]);
+        const bool dense = g.fkind[i] == PSGDK_DENSE;
+        const T* F = dense ? (const T*)(P->work + P->dn[g.fidx[i]].p_off) : (const T*)(P->state + P->dd[g.fidx[i]].a_off);
+        const int ldf = dense ? P->dn[g.fidx[i]].dp : 0;
+        const unsigned gb = (unsigned)std::min<int64_t>((numel + 255) / 256, 4096);
+        hipLaunchKernelGGL(gen_mode_apply_kernel<T>, dim3(gb), dim3(256), 0, st, cur, out, F, ldf, dense ? 1 : 0, (int)A, s_, (int)B,
+                           last ? sumsq : (float*)nullptr);
+        cur = out;
+        A *= s_;
+    }
+    return cur;
+}
+
 bool is_dense_dim(int64_t size, int64_t numel, double max_size, double max_skew) {
     // psgd.py:208  -- diagonal iff size <= 1 or size > max_size or size**2 > max_skew * numel
     return !(size <= 1 || (double)size > max_size || (double)size * (double)size > max_skew * (double)numel);
@@ -159,11 +188,25 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
         if (nd > 0 && !dims) return PSGDK_ERR_INVALID;
         int64_t numel = 1;
         for (int i = 0; i < nd; ++i) { if (dims[dpos + i] <= 0) return PSGDK_ERR_INVALID; numel *= dims[dpos + i]; }
-        if (nd > 2) return PSGDK_ERR_UNSUPPORTED;
+        if (nd > PSGDK_GEN_MAXDIM) return PSGDK_ERR_UNSUPPORTED;
         TensorDesc D{};
         D.numel = numel; D.row_diag = D.col_diag = D.row_dense = D.col_dense = -1;
         std::vector<FactorRef> fr;
-        if (nd <= 1) {
+        if (nd > 2) {
+            // N-D: contiguous logical array folded into rows of PSGDK_GEN_FOLD; factors applied mode by mode
+            D.kind = TK_GEN; D.transposed = 0;
+            D.lcols = D.C = D.Cp = PSGDK_GEN_FOLD;
+            D.lrows = D.R = D.Rp = (int)((numel + PSGDK_GEN_FOLD - 1) / PSGDK_GEN_FOLD);
+            GenDesc g{};
+            g.tensor = t; g.ndim = nd;
+            for (int i = 0; i < nd; ++i) {
+                g.dims[i] = (int)dims[dpos + i];
+                const bool dense = is_dense_dim(dims[dpos + i], numel, max_size, max_skew);
+                g.fkind[i] = dense ? PSGDK_DENSE : PSGDK_DIAG;
+                fr.push_back(FactorRef{dense ? PSGDK_DENSE : PSGDK_DIAG, -1});
+            }
+            P->gd.push_back(g);
+        } else if (nd <= 1) {
             const int64_t n = nd == 0 ? 1 : dims[dpos];
             // a 1-D tensor of size n: dense iff n^2 <= max_skew * n (psgd.py:208) -- only possible for tiny n / huge skew
             const bool dense = nd == 1 && is_dense_dim(n, numel, max_size, max_skew);
@@ -199,16 +242,22 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
         for (size_t i = 0; i < fr.size(); ++i) {
             // which canonical side does logical dim i sit on?
             bool is_row;
-            if (fr.size() == 1) is_row = false;                  // vectors / scalars: the column side
+            const bool gen = D.kind == TK_GEN;
+            if (fr.size() == 1 || gen) is_row = false;           // vectors / scalars: the column side
             else is_row = D.transposed ? (i == 1) : (i == 0);
-            const int len = is_row ? D.R : D.C;
+            int len = is_row ? D.R : D.C;
+            GenDesc* G_ = nullptr;
+            if (gen) {
+                for (auto& g : P->gd) if (g.tensor == t) G_ = &g;
+                len = G_->dims[i];
+            }
             if (fr[i].kind == PSGDK_DENSE) {
                 DenseDesc F{};
                 F.tensor = t; F.d = len; F.dp = (int)round_up64(len); F.is_row = is_row ? 1 : 0;
                 F.c = (float)((double)D.numel / (double)len);
                 fr[i].idx = (int)P->dn.size();
-                (is_row ? D.row_dense : D.col_dense) = fr[i].idx;
-                F.stream_id = 0x40000000u + ((unsigned)t * 2u + (unsigned)i) * 2u;
+                if (gen) G_->fidx[i] = fr[i].idx; else (is_row ? D.row_dense : D.col_dense) = fr[i].idx;
+                F.stream_id = 0x40000000u + ((unsigned)t * PSGDK_GEN_MAXDIM + (unsigned)i) * 2u;
                 P->dn.push_back(F);
                 P->dense_dim.push_back((int)i);
                 P->max_dp = std::max(P->max_dp, F.dp);
@@ -217,7 +266,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
                 G.tensor = t; G.len = len; G.is_row = is_row ? 1 : 0;
                 G.c = (float)((double)D.numel / (double)len);
                 fr[i].idx = (int)P->dd.size();
-                (is_row ? D.row_diag : D.col_diag) = fr[i].idx;
+                if (gen) G_->fidx[i] = fr[i].idx; else (is_row ? D.row_diag : D.col_diag) = fr[i].idx;
                 P->dd.push_back(G);
             }
         }
@@ -264,10 +313,14 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
         const TensorDesc& D = P->td[F.tensor];
         const int K = F.is_row ? D.Cp : D.Rp;
         F.slab_off = 0;
-        if (K > 4096) {
+        if (D.kind != TK_GEN && K > 4096) {
             const int nks = (K + 3071) / 3072;
             F.slab_off = wo; wo += align256((size_t)nks * F.dp * F.dp * 4);
         }
+    }
+    for (auto& g : P->gd) {
+        const size_t nb = align256((size_t)P->td[g.tensor].numel * esz);
+        g.pp_off[0] = wo; wo += nb; g.pp_off[1] = wo; wo += nb;
     }
     P->work_bytes = align256(wo);
     *out = P.release();
@@ -278,11 +331,11 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
     if (!plan || !ids) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;      // descriptors are uploaded at bind time
     for (int t = 0; t < plan->n_tensors; ++t) {
-        if (ids[t] >= 0x10000000u) return PSGDK_ERR_INVALID;
+        if (ids[t] >= 0x04000000u) return PSGDK_ERR_INVALID;
         plan->td[t].stream_id = ids[t];
     }
     for (size_t f = 0; f < plan->dn.size(); ++f)
-        plan->dn[f].stream_id = 0x40000000u + (ids[plan->dn[f].tensor] * 2u + (unsigned)plan->dense_dim[f]) * 2u;
+        plan->dn[f].stream_id = 0x40000000u + (ids[plan->dn[f].tensor] * PSGDK_GEN_MAXDIM + (unsigned)plan->dense_dim[f]) * 2u;
     return PSGDK_OK;
 }
 
@@ -348,6 +401,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if ((rc = upload(&P->d_td, P->td))) return rc;
     if ((rc = upload(&P->d_dd, P->dd))) return rc;
     if ((rc = upload(&P->d_dn, P->dn))) return rc;
+    if ((rc = upload(&P->d_gd, P->gd))) return rc;
     // ---- elementwise tile tables ----
     std::vector<EwTile> all, diag;
     P->tile_begin.assign(P->n_tensors + 1, 0);
@@ -386,6 +440,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     // ---- grouped GEMM stages (absolute pointers, so built at bind time) ----
     for (Stage* s : P->all_stages()) s->probs.clear();
     P->split_dense.clear();
+    P->gram_prob.clear();
     float* hsumsq = (float*)(W + P->hsumsq_off);
     for (size_t f = 0; f < P->dn.size(); ++f) {
         const DenseDesc& F = P->dn[f];
@@ -396,7 +451,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         g.A = S + F.qt_off; g.B = S + F.qt_off; g.C = W + F.p_off; g.Ct = g.C;
         g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
         P->g_P.probs.push_back(g);
-        // mode Gram term1 (psgd.py:405): col factor: Pgt Pgt^T; row factor: Pg Pg^T
+        // mode Gram term1 (psgd.py:405): col factor: Pgt Pgt^T; row factor: Pg Pg^T  (N-D tensors: kernels_gen.hiph)
+        P->gram_prob.push_back(D.kind == TK_GEN ? -1 : (int)P->g_gram.probs.size());
         g = GemmProblem{};
         const unsigned char* Z = W + (F.is_row ? D.pg_off : D.pgt_off);
         const int K = F.is_row ? D.Cp : D.Rp;
@@ -406,9 +462,9 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         g.row_sumsq = (float*)(W + F.rowss_off); g.diag_max = sc + DS_NF;
         if (F.slab_off) {
             g.flags |= GF_SPLITK; g.kchunk = 3072; g.slab = (float*)(W + F.slab_off);
-            P->split_dense.push_back((int)f);
+            if (D.kind != TK_GEN) P->split_dense.push_back((int)f);
         }
-        P->g_gram.probs.push_back(g);
+        if (D.kind != TK_GEN) P->g_gram.probs.push_back(g);
         // subspace iteration of norm_lower_bound_spd (A = term1) and _skh (A = R): V <- V (A/nf), psgd.py:65-67
         for (int chain = 0; chain < 2; ++chain)
             for (int p = 0; p < 4; ++p) {
@@ -579,7 +635,7 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         if (F) {
             std::vector<const void*> a(F), b(F);
             for (unsigned f = 0; f < F; ++f) {
-                const int slot = P->dn[f].tensor * 2 + P->dense_dim[f];
+                const int slot = P->dn[f].tensor * PSGDK_GEN_MAXDIM + P->dense_dim[f];
                 a[f] = noise->spd_noise[slot]; b[f] = noise->skh_noise[slot];
                 if (!a[f] || !b[f]) return PSGDK_ERR_INVALID;
             }
@@ -606,11 +662,35 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
                                          P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off)));
+    // N-D tensors: Pg mode by mode, then every mode's Gram (dense -> term1 + its row stats; diagonal -> the sum vector)
+    for (const GenDesc& g : P->gd) {
+        const TensorDesc& D = P->td[g.tensor];
+        DISPATCH_T(P, {
+            const T* Pg = gen_apply_chain<T>(P, g, (const T*)(P->work + D.x_off), (T*)nullptr, (float*)nullptr, st);
+            int64_t A = 1;
+            for (int i = 0; i < g.ndim; ++i) {
+                const int s_ = g.dims[i];
+                const int64_t B = D.numel / (A * s_);
+                if (g.fkind[i] == PSGDK_DENSE) {
+                    const DenseDesc& Fd = P->dn[g.fidx[i]];
+                    T* T1 = (T*)(P->work + Fd.t1_off);
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1, Fd.dp,
+                                       (float*)nullptr);
+                    hipLaunchKernelGGL(gen_rowstats_kernel<T>, dim3(s_), dim3(256), 0, st, (const T*)T1, s_, Fd.dp,
+                                       (float*)(P->work + Fd.rowss_off), (float*)(P->work + Fd.sc_off) + DS_NF);
+                } else {
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, 1), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 0, (T*)nullptr, 0,
+                                       (float*)(P->work + P->dd[g.fidx[i]].sum_off));
+                }
+                A *= s_;
+            }
+        });
+    }
     if (F) {
         launch_stage(P, P->g_gram, st);
         for (int f : P->split_dense) {
             const DenseDesc& D = P->dn[f];
-            const GemmProblem& g = P->g_gram.probs[f];
+            const GemmProblem& g = P->g_gram.probs[P->gram_prob[f]];
             const int nks = (g.K + g.kchunk - 1) / g.kchunk;
             DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((D.dp + 255) / 256, D.dp), dim3(256), 0, st,
                                              (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, g.row_sumsq, g.diag_max, D.d));
@@ -637,7 +717,11 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     // balancing (psgd.py:418-419)
     if (balance_mask) {
         std::vector<int> which;
-        for (int t = 0; t < P->n_tensors; ++t) if (balance_mask[t] && P->factors[t].size() > 1) which.push_back(t);
+        for (int t = 0; t < P->n_tensors; ++t)
+            if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN) which.push_back(t);
+        for (size_t gi = 0; gi < P->gd.size(); ++gi)
+            if (balance_mask[P->gd[gi].tensor])
+                DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
         if (!which.empty()) {
             HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(P->d_balnorm, 0, 2 * which.size() * sizeof(float), st));
@@ -663,6 +747,13 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     if ((rc = ensure_P(P, st))) return rc;
     launch_stage(P, P->g_app_a[source], st);
     launch_stage(P, P->g_app_b, st);
+    for (const GenDesc& g : P->gd) {
+        const TensorDesc& D = P->td[g.tensor];
+        DISPATCH_T(P, {
+            const T* src = source == PSGDK_SRC_GRAD ? (const T*)(P->work + D.gc_off) : (const T*)(P->state + D.ema_off);
+            gen_apply_chain<T>(P, g, src, (T*)(P->work + D.h_off), (float*)(P->work + P->hsumsq_off) + g.tensor, st);
+        });
+    }
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
                                          P->d_tiles_diag, P->state, P->work, 1, source == PSGDK_SRC_GRAD ? 1 : 0,

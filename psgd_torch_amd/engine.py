@@ -94,6 +94,12 @@ class KronEngine:
                 L.check(self.lib.psgdk_plan_ema_view(self._plan, t, C.byref(off), C.byref(rows), C.byref(cols),
                                                      C.byref(ld), C.byref(tr)), "ema_view")
                 r, c, l_ = rows.value, cols.value, ld.value
+                if len(self.shapes[t]) > 2:        # N-D tensors are held as the contiguous logical array
+                    numel = 1
+                    for x in self.shapes[t]:
+                        numel *= x
+                    self.ema.append(self._typed(off.value, numel, self.dtype).view(self.shapes[t]))
+                    continue
                 if tr.value:
                     base = self._typed(off.value, (c - 1) * l_ + r, self.dtype)
                     v = torch.as_strided(base, (r, c), (1, l_))
@@ -147,12 +153,12 @@ class KronEngine:
             g_noise, spd, skh = noise
             gl = [x.to(self.dtype).contiguous() for x in g_noise]
             ga = L.ptr_array(gl)
-            sa = (C.c_void_p * (2 * self.n))()
-            ka = (C.c_void_p * (2 * self.n))()
+            sa = (C.c_void_p * (8 * self.n))()      # PSGDK_MAX_DIMS slots per tensor
+            ka = (C.c_void_p * (8 * self.n))()
             for (t, i), x in spd.items():
-                x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * 2 + i] = x.data_ptr()
+                x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * 8 + i] = x.data_ptr()
             for (t, i), x in skh.items():
-                x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * 2 + i] = x.data_ptr()
+                x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * 8 + i] = x.data_ptr()
             nz = L.Noise(C.cast(ga, C.POINTER(C.c_void_p)), C.cast(sa, C.POINTER(C.c_void_p)),
                          C.cast(ka, C.POINTER(C.c_void_p)))
             keep += [gl, ga, sa, ka, nz]

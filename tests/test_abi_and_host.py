@@ -49,7 +49,8 @@ def _plan(lib, shapes, max_size=float("inf"), max_skew=1.0, dtype=0, mom=1):
 @pytest.mark.parametrize("max_size,max_skew", [(float("inf"), 1.0), (float("inf"), float("inf")), (30, float("inf")),
                                                (float("inf"), 0.0), (float("inf"), 2.0), (100, 0.5)])
 def test_plan_factor_kinds_match_init_kron_rule(lib, max_size, max_skew):
-    shapes = [(), (33,), (48, 32), (32, 48), (64, 64), (40, 8), (1, 16), (6, 26), (257, 120), (768, 96), (1024, 768), (5,), (2, 2)]
+    shapes = [(), (33,), (48, 32), (32, 48), (64, 64), (40, 8), (1, 16), (6, 26), (257, 120), (768, 96), (1024, 768), (5,), (2, 2),
+              (7, 5, 3), (4, 6, 5, 3), (64, 32, 3, 3)]
     rc, plan = _plan(lib, shapes, max_size, max_skew)
     assert rc == 0
     for t, s in enumerate(shapes):
@@ -73,7 +74,10 @@ def test_plan_factor_kinds_match_init_kron_rule(lib, max_size, max_skew):
 def test_plan_argument_errors(lib):
     from psgd_torch_amd import _lib
     rc, plan = _plan(lib, [(3, 4, 5)])
-    assert rc == _lib.PSGDK_ERR_UNSUPPORTED            # > 2 non-singleton dims: not built yet, refused loudly
+    assert rc == 0                                     # 3..8 dims: generic mode-product path
+    lib.psgdk_plan_destroy(plan)
+    rc, plan = _plan(lib, [tuple([2] * 9)])
+    assert rc == _lib.PSGDK_ERR_UNSUPPORTED            # > PSGDK_MAX_DIMS dims: refused loudly
     rc, plan = _plan(lib, [tuple([2] * 27)])
     assert rc == _lib.PSGDK_ERR_INVALID                # psgd.py:197-198
     rc, plan = _plan(lib, [(4, 0)])

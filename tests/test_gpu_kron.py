@@ -79,7 +79,7 @@ def _noise_to_dev(noise, dt):
     return (g, spd, skh)
 
 
-KRON_2D = [n for n in golden_names("kron_") if len(load(n)["shape"]) <= 2]
+KRON_2D = golden_names("kron_")       # <= 2-D tensors (grouped-GEMM path) and N-D tensors (mode-product path)
 
 
 @pytest.mark.parametrize("name", KRON_2D)
