@@ -40,7 +40,8 @@ struct psgdk_plan {
     GenDesc* d_gd = nullptr;
     std::vector<int> gram_prob;                      // per dense factor: its problem in g_gram, or -1 (N-D tensors)
     size_t state_bytes = 0, work_bytes = 0;
-    size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0;
+    size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0, diag_mu_off = 0;
+    int max_diag_len = 0;
     unsigned char* state = nullptr;
     unsigned char* work = nullptr;
     // device tables owned by the plan
@@ -297,6 +298,8 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
     P->zero_bytes = wo - P->zero_off;
     P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
+    P->diag_mu_off = wo; wo += align256((P->dd.size() + 1) * 4);
+    for (auto& G : P->dd) P->max_diag_len = std::max(P->max_diag_len, G.len);
     for (auto& D : P->td) {
         const size_t mb = align256((size_t)D.Rp * D.Cp * esz);
         D.gc_off = wo; wo += mb; D.x_off = wo; wo += mb; D.h_off = wo; wo += mb;
@@ -692,7 +695,7 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
             const DenseDesc& D = P->dn[f];
             const GemmProblem& g = P->g_gram.probs[P->gram_prob[f]];
             const int nks = (g.K + g.kchunk - 1) / g.kchunk;
-            DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((D.dp + 255) / 256, D.dp), dim3(256), 0, st,
+            DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((unsigned)((D.dp / 64) * (D.dp / 64 + 1) / 2)), dim3(256), 0, st,
                                              (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, g.row_sumsq, g.diag_max, D.d));
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
@@ -712,8 +715,14 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     }
     // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
     if (!P->dd.empty())
+    {
+        float* mu = (float*)(P->work + P->diag_mu_off);
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
-                                         P->work, lr, betaL));
+                                         P->work, mu, 0, lr, betaL));
+        const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
+                                         P->state, P->work, mu, 1, lr, betaL));
+    }
     // balancing (psgd.py:418-419)
     if (balance_mask) {
         std::vector<int> which;
