@@ -20,6 +20,7 @@ struct Stage {                       // one grouped GEMM launch
     GemmProblem* d_probs = nullptr;
     GemmTile* d_tiles = nullptr;
     unsigned n_tiles = 0;
+    bool big = false;                // 256x128 / 8-wave tiling (gemm_nt_big_kernel)
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -91,6 +92,7 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
+    tb.bm = s.big ? GEMM_BIG_BM : GEMM_BM;
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
@@ -101,7 +103,9 @@ int finish_stage(Stage& s) {
 
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
-    if (s.n_tiles) hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
+    if (!s.n_tiles) return;
+    if (s.big) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
+    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
 }
 void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
@@ -841,8 +845,9 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     GemmProblem P{};
     P.A = A; P.B = B; P.C = C; P.Ct = Ct;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldct = ldct;
-    P.alpha = 1.0f; P.flags = symmetric ? GF_SYM : 0;
-    if (symmetric) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
+    P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
+    if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
+    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x128 tiling
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -850,6 +855,7 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
         if (dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st);
         if (hipGetLastError() != hipSuccess) rc = PSGDK_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) rc = PSGDK_ERR_HIP;
+        if (rc == PSGDK_ERR_HIP) g_last_hip_error = (int)hipGetLastError();
     }
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_tiles) (void)hipFree(s.d_tiles);
@@ -870,9 +876,11 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
         P.Ct = Ct ? (unsigned char*)Ct + (size_t)b * M * N * esz : nullptr;
         P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = K; P.ldc = N; P.ldct = M;
         P.alpha = 1.0f; P.flags = (symmetric & 1 ? GF_SYM : 0) | (symmetric & ~1);
-        if (symmetric) { P.Ct = P.C; P.ldct = P.ldc; }
+        if (symmetric & 1) { P.Ct = P.C; P.ldct = P.ldc; }
         s.probs.push_back(P);
     }
+    s.big = (symmetric & 1024) != 0;
+    for (auto& q : s.probs) q.flags &= ~1024;
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;

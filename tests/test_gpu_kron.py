@@ -36,25 +36,27 @@ def test_native_library_loaded():
     assert torch.cuda.is_available()
 
 
+@pytest.mark.parametrize("big", [0, 1024])
 @pytest.mark.parametrize("dt,code,tol", [(torch.bfloat16, 0, 2e-2), (torch.float32, 1, 2e-6)])
-def test_gemm_kernel(dt, code, tol):
+def test_gemm_kernel(dt, code, tol, big):
+    """Both tilings of the grouped NT GEMM (128x128 / 4 waves, 256x128 / 8 waves): plain, transposed, symmetric."""
     from psgd_torch_amd import _lib
     lib = _lib.lib()
     st = _lib.current_stream()
     torch.manual_seed(0)
-    for (M, N, K) in ((128, 128, 64), (64, 64, 64), (192, 320, 128), (768, 768, 768), (2304, 768, 768), (64, 192, 1024)):
+    for (M, N, K) in ((128, 128, 64), (64, 64, 64), (192, 320, 128), (768, 768, 768), (2304, 768, 768), (64, 192, 1024), (320, 64, 192)):
         A = torch.randn(M, K, device=DEV).to(dt)
         B = torch.randn(N, K, device=DEV).to(dt)
         Cc = torch.zeros(M, N, device=DEV, dtype=dt)
         Ct = torch.zeros(N, M, device=DEV, dtype=dt)
-        _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), B.data_ptr(), Cc.data_ptr(), Ct.data_ptr(), code, M, N, K, K, K, N, M, 0, st))
+        _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), B.data_ptr(), Cc.data_ptr(), Ct.data_ptr(), code, M, N, K, K, K, N, M, big, st))
         ref = A.double() @ B.double().t()
-        assert relerr(Cc, ref) < tol and relerr(Ct.t(), ref) < tol
-    for (M, K) in ((128, 64), (192, 256), (768, 2304)):
+        assert relerr(Cc, ref) < tol and relerr(Ct.t(), ref) < tol, (M, N, K)
+    for (M, K) in ((128, 64), (192, 256), (768, 2304), (320, 128)):
         A = torch.randn(M, K, device=DEV).to(dt)
         Cc = torch.full((M, M), float("nan"), device=DEV, dtype=dt)
-        _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), A.data_ptr(), Cc.data_ptr(), None, code, M, M, K, K, K, M, M, 1, st))
-        assert relerr(Cc, A.double() @ A.double().t()) < tol
+        _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), A.data_ptr(), Cc.data_ptr(), None, code, M, M, K, K, K, M, M, 1 | big, st))
+        assert relerr(Cc, A.double() @ A.double().t()) < tol, (M, K)
         assert torch.equal(Cc, Cc.t()), "mode Gram must be bitwise symmetric (SURVEY H1)"
 
 

@@ -23,7 +23,10 @@ run(768, 768, 768, batch=62); run(768, 768, 768, batch=62, mode="CT"); run(768, 
 run(768, 768, 3072, batch=48, sym=1)
 run(4096, 4096, 4096); run(8192, 8192, 8192, iters=5)
 run(16384, 768, 768, dt=torch.float32); run(4096, 4096, 4096, dt=torch.float32, iters=5)
-print("--- debug: no epilogue (256), no main loop (512), neither (768)")
-for flag in (0, 256, 512, 768):
-    run(16384, 768, 768, sym=flag)
-    run(16384, 768, 64, sym=flag)
+print("--- big tiling (256x128, 8 waves, 3-stage ring) vs small")
+for shape in ((16384, 768, 768, 1), (16384, 768, 3072, 1), (768, 768, 768, 62), (4096, 4096, 4096, 1)):
+    M, N, K, b = shape
+    for flag in (0, 1024):
+        run(M, N, K, batch=b, sym=flag)
+run(768, 768, 768, batch=62, mode="CT", sym=1024); run(768, 768, 768, batch=62, sym=1025); run(768, 768, 3072, batch=48, sym=1025)
+run(16384, 768, 768, mode="T", sym=1024); run(8192, 8192, 8192, sym=1024, iters=5)
