@@ -234,3 +234,40 @@ def test_known_answer_whitening(shape, max_skew):
     h = amd.precond_grad_kron(QL, exprs, G)
     err = relerr(h, V)
     assert err < 0.08, (shape, max_skew, err)
+
+
+def test_kronwhiten_closure_shell():
+    """psgd.py:516-654 restated on the engine: (1) same trajectory as KWNS4 with identical settings and weight decay 0
+    (both drive the same batched engine calls with the same Philox streams); (2) it optimises: a least-squares problem
+    with an ill-conditioned design converges by orders of magnitude (cf. the reference's demo plots)."""
+    amd = _amd()
+    from psgd_torch_amd.kron_whiten import KronWhiten
+    torch.manual_seed(0)
+    shapes = [(24, 40), (40,), (16, 16), (3, 4, 5)]
+    g = torch.Generator().manual_seed(4)
+    p_a = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    p_b = [torch.nn.Parameter(p.detach().clone()) for p in p_a]
+    targets = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    scales = [(0.1 + 3 * torch.rand(s, generator=g)).to(DEV) for s in shapes]
+    kw = dict(lr_params=0.05, lr_preconditioner=0.3, momentum=0.9, preconditioner_max_skew=2.0)
+    opt_a = KronWhiten(p_a, preconditioner_init_scale=1.0, whiten_grad=False, **kw)
+    opt_b = amd.KWNS4(p_b, preconditioner_dtype=None, weight_decay=0.0, whiten_grad=False, **kw)
+
+    def loss_of(ps):
+        return sum((((p - t) * s) ** 2).sum() for p, t, s in zip(ps, targets, scales))
+    l0 = float(loss_of(p_a))
+    for it in range(60):
+        opt_a.step(lambda: loss_of(p_a))
+        opt_b.zero_grad()
+        loss_of(p_b).backward()
+        opt_b.step()
+    for a, b in zip(p_a, p_b):
+        assert relerr(a.data, b.data) < 1e-4, relerr(a.data, b.data)
+    assert float(loss_of(p_a)) < 0.05 * l0, (l0, float(loss_of(p_a)))
+    # on-the-fly initial scale (psgd.py:599-602) + gradient whitening without momentum
+    p_c = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    opt_c = KronWhiten(p_c, lr_params=0.05, lr_preconditioner=0.3)
+    l0 = float(loss_of(p_c))
+    for it in range(80):
+        opt_c.step(lambda: loss_of(p_c))
+    assert float(loss_of(p_c)) < 0.2 * l0
