@@ -75,6 +75,42 @@ def cpu_baseline(seconds_budget=12.0):
                       f"median of {len(times) - 1} steps, {steady * 1e3:.0f} ms/step"}
 
 
+def bench_lra(args):
+    """BASELINE config 4: ViT-B/16 parameter count (N = 86,543,080), LRA rank 10, fp32: update_precond_lra_whiten +
+    precond_grad_lra per step (psgd.py:1066, 1055).  HBM-bound: algorithmic bytes = 9 matrix reads + 3 matrix writes
+    (update) + 3 matrix reads (apply), matrix pass = N*r*4 bytes, plus ~24 N-vector passes."""
+    from psgd_torch_amd import lra
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    N, r = 86543080, 10
+    gen = torch.Generator(device=dev).manual_seed(0)
+    U = torch.randn(N, r, device=dev, generator=gen); U *= 0.1 ** 0.5 / torch.linalg.vector_norm(U)
+    V = torch.randn(N, r, device=dev, generator=gen); V *= 0.1 ** 0.5 / torch.linalg.vector_norm(V)
+    UVd = [U, V, torch.ones(N, 1, device=dev)]
+    Luvd = [torch.zeros([], device=dev) for _ in range(3)]
+    g = 0.01 * torch.randn(N, 1, device=dev, generator=gen)
+
+    def one_step():
+        lra.update_precond_lra_whiten(UVd, Luvd, g, lr=0.1, betaL=0.9, damping=1e-9)
+        return lra.precond_grad_lra(UVd, g)
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / args.steps
+    bytes_alg = (12 + 3) * N * r * 4 + 24 * N * 4
+    out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "fp32", "data": "synthetic",
+           "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra"},
+           "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": None, "algorithmic_gb_per_step": bytes_alg / 1e9}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +118,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
+    ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra"],
+                    help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
     args = ap.parse_args()
+    if args.config == "vit-b-lra":
+        return bench_lra(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +139,13 @@ def main():
         torch.distributed.init_process_group(backend="nccl", device_id=dev)
 
     import psgd_torch_amd
-    shapes = gpt2_shapes()
+    if args.config == "gpt2-medium":
+        shapes = gpt2_shapes(n_layer=24, n_embd=1024)
+    elif args.config == "lenet5":
+        shapes = [(6, 26), (16, 151), (257, 120), (121, 84), (85, 10)]      # mnist_with_lenet5.py:20-24
+        args.fp32 = True
+    else:
+        shapes = gpt2_shapes()
     nparam = sum(math.prod(s) for s in shapes)
     gen = torch.Generator(device=dev).manual_seed(1234)
     params = [torch.nn.Parameter(0.02 * torch.randn(*s, device=dev, generator=gen)) for s in shapes]
@@ -147,6 +193,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     step_flops, gemm_flops = flop_model(shapes)
+    run_cpu = args.config == "gpt2-small"
     out = {
         "metric": "psgd_kron_step_throughput",
         "value": nparam / (dt / args.steps) / 1e9,
@@ -160,9 +207,11 @@ def main():
         "vs_baseline": None,
         "dtype": "fp32" if args.fp32 else "bf16",
         "data": "synthetic",
-        "config": {"workload": "GPT-2-small parameter shapes (misc/gpt2.py GPTConfig defaults): 148 tensors, "
-                               f"{nparam} params, 62 dense 768x768 Kron factors; KWNS4 defaults "
-                               "(momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
+        "config": {"workload": {"gpt2-small": "GPT-2-small parameter shapes (misc/gpt2.py GPTConfig defaults): 148 tensors, "
+                                              f"{nparam} params, 62 dense 768x768 Kron factors",
+                                "gpt2-medium": f"GPT-2-medium parameter shapes (24 layers, d=1024): {len(shapes)} tensors, {nparam} params",
+                                "lenet5": f"LeNet5 parameter shapes (mnist_with_lenet5.py): 5 tensors, {nparam} params, fp32"}[args.config]
+                               + "; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
                    "parallelism": "single GPU" if world == 1 else f"per-parameter state sharding x{world} + all-gather",
                    "step_gflop_model": step_flops / 1e9},
@@ -175,7 +224,7 @@ def main():
         # HBM bytes per launch come from a separate rocprofv3 --pmc run (profiles/): counters cannot be read in-process
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if os.path.exists(tpath) and not args.fp32:
+        if os.path.exists(tpath) and not args.fp32 and args.config == "gpt2-small":
             try:
                 traffic = json.load(open(tpath))["kernels"]["gemm_nt_kernelIt"]["hbm_bytes_per_launch_corrected"]
             except Exception:
@@ -188,7 +237,7 @@ def main():
                            "gemm_ms_per_step": gemm_ms / args.steps,
                            "whole_step_frac_of_peak": step_flops / (dt / args.steps) / 1e12 / peak}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and run_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist:
