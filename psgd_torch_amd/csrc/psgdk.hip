@@ -235,6 +235,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
             fr.push_back(FactorRef{d1 ? PSGDK_DENSE : PSGDK_DIAG, -1});
         }
         D.stream_id = (unsigned)t;
+        D.wide = (!D.transposed && D.C >= 256 && D.R >= 4) ? 1 : 0;
         P->td.push_back(D);
         P->factors.push_back(fr);
         P->order.push_back(nd == 0 ? 1 : nd);
@@ -415,11 +416,12 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     for (int t = 0; t < P->n_tensors; ++t) {
         const TensorDesc& D = P->td[t];
         P->tile_begin[t] = (unsigned)all.size();
-        for (int tr = 0; tr < (D.R + 63) / 64; ++tr)
-            for (int tc = 0; tc < (D.C + 63) / 64; ++tc) {
-                all.push_back(EwTile{t, tr, tc});
-                if (D.kind == TK_VEC || D.kind == TK_DD) diag.push_back(EwTile{t, tr, tc});
-            }
+        const int th = D.wide ? 16 : 64, tw = D.wide ? 256 : 64;
+        for (int tr = 0; tr < (D.R + th - 1) / th; ++tr)
+            for (int tc = 0; tc < (D.C + tw - 1) / tw; ++tc) all.push_back(EwTile{t, tr, tc});
+        if (D.kind == TK_VEC || D.kind == TK_DD)
+            for (int tr = 0; tr < (D.R + 63) / 64; ++tr)
+                for (int tc = 0; tc < (D.C + 63) / 64; ++tc) diag.push_back(EwTile{t, tr, tc});
     }
     P->tile_begin[P->n_tensors] = (unsigned)all.size();
     P->n_tiles_all = (unsigned)all.size(); P->n_tiles_diag = (unsigned)diag.size();

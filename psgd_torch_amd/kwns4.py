@@ -176,6 +176,9 @@ class KWNS4(torch.optim.Optimizer):
                 b.h_views.append(b.flat[offs[r]:offs[r] + numels[i]].view(s))
                 offs[r] += numels[i]
         self._buckets[key] = b
+        pending = getattr(self, "_pending_restore", None)
+        if pending:                      # load_state_dict() was called before the buckets existed
+            self._restore_bucket(b, pending.pop(0))
         return b
 
     @torch.no_grad()
@@ -248,3 +251,42 @@ class KWNS4(torch.optim.Optimizer):
                 torch.distributed.broadcast(p, src=0)
             if eng is not None:
                 torch.distributed.broadcast(eng.state_arena, src=0)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # checkpoint / resume.  The reference offers none that works: its state holds opt_einsum expression objects and its
+    # private RNG states live outside `state`.  Here the whole engine state of a bucket is one arena
+    # tensor (Q, Qt, diagonal factors, L, ema) plus two counters and the host gate generator's state.
+    def state_dict(self):
+        buckets = []
+        for key, b in self._buckets.items():
+            buckets.append({
+                "group": key[0], "n_params": len(b.params), "owned": list(b.owned), "step": b.step,
+                "arena": b.engine.state_arena.detach().clone().cpu() if b.engine is not None else None,
+            })
+        return {"psgdk_version": 1, "state": {},      # per-parameter state lives in the bucket arenas below
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
+
+    def load_state_dict(self, sd):
+        """Restores a state_dict() taken from an optimizer over the SAME parameters (same order, shapes, dtypes, sharding).
+        Buckets are built lazily, so this may be called right after construction; the arenas are filled at the first step."""
+        assert sd.get("psgdk_version") == 1, "not a psgd_torch_amd.KWNS4 state dict"
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
+        self._global_step = sd["global_step"]
+        self._seed = sd["seed"]
+        self._gate_gen.set_state(sd["gate_rng"])
+        self._pending_restore = list(sd["buckets"])
+        for b, saved in zip(self._buckets.values(), self._pending_restore):
+            self._restore_bucket(b, saved)
+        if self._buckets:
+            self._pending_restore = []
+
+    def _restore_bucket(self, b, saved):
+        assert saved["n_params"] == len(b.params) and saved["owned"] == list(b.owned), "checkpoint does not match this optimizer"
+        b.step = saved["step"]
+        for p in b.params:
+            self.state[p]["step"] = saved["step"]
+        if b.engine is not None:
+            b.engine.state_arena.copy_(saved["arena"].to(b.engine.state_arena.device))
+            b.engine.state_changed()

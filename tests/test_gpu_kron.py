@@ -271,3 +271,30 @@ def test_kronwhiten_closure_shell():
     for it in range(80):
         opt_c.step(lambda: loss_of(p_c))
     assert float(loss_of(p_c)) < 0.2 * l0
+
+
+def test_kwns4_checkpoint_resume():
+    """state_dict()/load_state_dict(): 3 steps + save + 3 steps == 3 steps, fresh optimizer, load, 3 steps."""
+    amd = _amd()
+    shapes = [(96, 64), (64,), (64, 64), (4, 5, 6)]
+    g = torch.Generator().manual_seed(8)
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[0.3 * torch.randn(s, generator=g) for s in shapes] for _ in range(6)]
+
+    def run(opt, params, rng):
+        for t in rng:
+            for p, gr in zip(params, grads[t]):
+                p.grad = gr.to(DEV)
+            opt.step()
+    pa = [torch.nn.Parameter(x.clone().to(DEV)) for x in init]
+    oa = amd.KWNS4(pa, preconditioner_dtype=torch.float32, lr_params=1e-2, preconditioner_update_probability=0.7)
+    run(oa, pa, range(3))
+    sd = oa.state_dict()
+    snap = [p.detach().clone() for p in pa]
+    run(oa, pa, range(3, 6))
+    pb = [torch.nn.Parameter(x.clone()) for x in snap]
+    ob = amd.KWNS4(pb, preconditioner_dtype=torch.float32, lr_params=1e-2, preconditioner_update_probability=0.7)
+    ob.load_state_dict(sd)
+    run(ob, pb, range(3, 6))
+    for a, b in zip(pa, pb):
+        assert relerr(a.data, b.data) < 1e-6, relerr(a.data, b.data)
