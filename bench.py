@@ -178,6 +178,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
+    host_dt = time.perf_counter() - t0          # host enqueue time (no sync inside): shows whether the host keeps ahead
     fence()
     dt = time.perf_counter() - t0
     gemm_ms, gemm_launches = 0.0, 0
@@ -214,7 +215,7 @@ def main():
                                + "; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
                    "parallelism": "single GPU" if world == 1 else f"per-parameter state sharding x{world} + all-gather",
-                   "step_gflop_model": step_flops / 1e9},
+                   "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3},
     }
     if world == 1 and gemm_launches:
         launches_per_step = gemm_launches / args.steps

@@ -51,6 +51,8 @@ struct psgdk_plan {
     std::vector<unsigned> tile_begin;                // per tensor range in d_tiles_all
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
+    std::vector<const void*> h_ptr_a, h_ptr_b;              // what the device tables currently hold (uploads are skipped
+                                                            // when a call passes the same addresses as the previous one)
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
     int* d_balance = nullptr; float* d_balnorm = nullptr;
@@ -579,6 +581,14 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream) {
     return PSGDK_OK;
 }
 
+static int upload_ptrs(void** dst, std::vector<const void*>& cache, const void* const* src, size_t n, hipStream_t st) {
+    if (cache.size() == n && std::memcmp(cache.data(), src, n * sizeof(void*)) == 0) return PSGDK_OK;
+    cache.assign(src, src + n);
+    // the source is the plan-owned cache (stable until the next differing call), not the caller's array
+    HIPCHK(hipMemcpyAsync(dst, cache.data(), n * sizeof(void*), hipMemcpyHostToDevice, st));
+    return PSGDK_OK;
+}
+
 int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype, const void* const* params,
                      int param_dtype, float coupled_wd, float beta, int keep_grad, const psgdk_damp* damp, void* stream) {
     if (!plan || !grads) return PSGDK_ERR_INVALID;
@@ -588,8 +598,9 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     if (!(beta >= 0.f && beta < 1.f)) return PSGDK_ERR_INVALID;
     for (int t = 0; t < plan->n_tensors; ++t) if (!grads[t] || (coupled_wd != 0.f && !params[t])) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(plan->d_ptr_a, grads, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
-    if (coupled_wd != 0.f) HIPCHK(hipMemcpyAsync(plan->d_ptr_b, params, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+    int rcp;
+    if ((rcp = upload_ptrs(plan->d_ptr_a, plan->h_ptr_a, grads, plan->n_tensors, st))) return rcp;
+    if (coupled_wd != 0.f && (rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)params, plan->n_tensors, st))) return rcp;
     const int keep = (keep_grad || !plan->use_momentum) ? 1 : 0;
     // optional fusion of the update's damped input X (psgd.py:402-403) into this pass (saves one read of the source)
     plan->x_valid = false;
@@ -784,10 +795,11 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
     if (!(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
     for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(plan->d_ptr_b, params, plan->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+    int rcp;
+    if ((rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)params, plan->n_tensors, st))) return rcp;
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td, plan->d_tiles_all,
                                         (void* const*)plan->d_ptr_b, param_dtype, plan->work,
-                                        (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp));
+                                        (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp, (void*)nullptr));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }
@@ -797,11 +809,10 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
     if (!plan || t < 0 || t >= plan->n_tensors || !out || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(plan->d_ptr_a, &out, sizeof(void*), hipMemcpyHostToDevice, st));
     const unsigned b = plan->tile_begin[t], e = plan->tile_begin[t + 1];
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(e - b), dim3(256), 0, st, plan->d_td, plan->d_tiles_all + b,
                                         (void* const*)plan->d_ptr_a, out_dtype, plan->work,
-                                        (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp));
+                                        (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, out));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }
