@@ -226,6 +226,64 @@ def update_precond_kron_whiten_q0p5eq1p5(QL, G: Tensor, noise: KronNoise, lr: fl
     return inter
 
 
+def apply_q_kron(Q: List[Tensor], X: Tensor) -> Tensor:
+    """exprA (psgd.py:248-249): A = (kron_i Q_i) X, one factor per mode."""
+    if X.dim() == 0:
+        return Q[0] * X
+    for i, q in enumerate(Q):
+        X = _mode_scale(q, X, i) if q.dim() < 2 else _mode_product(q, X, i)
+    return X
+
+
+def solve_q_kron(Q: List[Tensor], V: Tensor) -> Tensor:
+    """psgd.py:288-303: conjB = V x_i Q_i^{-T} -- per mode a right triangular solve (in fp32 for bf16, lift2single,
+    rounded back to V's dtype after every mode) or a division by the diagonal factor.  Returned in V's own dim order
+    (the reference carries it cyclically permuted; its Grams are order independent)."""
+    if V.dim() == 0:
+        return V / Q[0]
+    B = V
+    for i, q in enumerate(Q):
+        Bm = B.movedim(i, -1)
+        if q.dim() < 2:
+            Bm = Bm / q
+        else:
+            shp = Bm.shape
+            Y = torch.linalg.solve_triangular(lift2single(q), lift2single(Bm.reshape(-1, shp[-1])), upper=True, left=False)
+            Bm = Y.to(B.dtype).reshape(shp)
+        B = Bm.movedim(-1, i)
+    return B
+
+
+def update_precond_kron_eq(QL, V: Tensor, Hvp: Tensor, spd_noise: List[Optional[Tensor]], balance_u: float,
+                           lr: float = 0.1, betaL: float = 0.9) -> None:
+    """psgd.py:278-319, in place on Q and L: the triangular geometry dQ = E*Q."""
+    Q, L = QL
+    A = apply_q_kron(Q, Hvp)
+    B = solve_q_kron(Q, V)
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        term1 = gram_mode(A, i, dense)
+        term2 = gram_mode(B, i, dense)
+        if not dense:
+            ell = torch.max(term1 + term2)
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.sub_(lr / L[i] * (term1 - term2) * q)
+        else:
+            ell = norm_lower_bound_spd(term1 + term2, spd_noise[i])
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.sub_(lr / L[i] * torch.triu(term1 - term2) @ q)
+    if balance_u < 0.01:
+        balance_kron_precond(Q)
+
+
+def update_precond_kron_whiten_eq(QL, G: Tensor, noise: KronNoise, lr: float = 0.1, betaL: float = 0.9,
+                                  damping: float = 1e-9) -> None:
+    """psgd.py:330-336: V = noise.g_noise is both the probe and the damping noise; noise.skh is unused."""
+    V = noise.g_noise.to(G.dtype)
+    damp = damping + torch.finfo(G.dtype).eps * G.abs()
+    update_precond_kron_eq(QL, V, G + damp * V, noise.spd, noise.balance_u, lr=lr, betaL=betaL)
+
+
 # --------------------------------------------------------------------------------------------
 # LRA preconditioner
 # --------------------------------------------------------------------------------------------

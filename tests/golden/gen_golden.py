@@ -275,6 +275,53 @@ def gen_kron():
                   betaL=0.5, damping=1e-3, seed=40)
 
 
+def gen_kron_eq_case(name, shape, dtypes, T, max_skew=1.0, max_size=float("inf"), Scale=1.0, lr=0.2, betaL=0.9,
+                     damping=1e-9, force_balance_at=None, seed=0):
+    """The triangular geometry dQ = E*Q (psgd.py:278-336): init_kron(dQ="EQ") + update_precond_kron_whiten_eq."""
+    out = {"shape": np.asarray(shape, dtype=np.int64), "T": np.asarray(T), "max_skew": np.asarray(max_skew),
+           "max_size": np.asarray(max_size), "Scale": np.asarray(Scale), "lr": np.asarray(lr),
+           "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
+    G32 = structured_grads(shape, T, seed + 1)
+    for t in range(T):
+        out[f"G{t}"] = npy(G32[t])
+    for dn in dtypes:
+        dt = DT[dn]
+        QL, exprs = psgd.init_kron(G32[0].to(dt), Scale=Scale, max_size=max_size, max_skew=max_skew, dQ="EQ")
+        torch.manual_seed(2000 + seed)
+        for t in range(T):
+            G = G32[t].to(dt)
+            ndense = sum(1 for q in QL[0] if q.dim() == 2)
+            force = [0.001 if force_balance_at == t else 0.5]
+            with Recorder(force_rand=force) as r:
+                psgd.update_precond_kron_whiten_eq(QL, exprs, G, lr=lr, betaL=betaL, damping=damping)
+            assert len(r.draws) == 1 + ndense + 1, (len(r.draws), ndense)
+            out[f"{dn}_t{t}_gnoise"] = npy(r.draws[0][1])
+            k = 1
+            for i, q in enumerate(QL[0]):
+                if q.dim() == 2:
+                    out[f"{dn}_t{t}_spd{i}"] = npy(r.draws[k][1])
+                    k += 1
+            out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1])
+            out[f"{dn}_t{t}_h"] = npy(psgd.precond_grad_kron(QL, exprs, G))
+            for i, (q, ell) in enumerate(zip(*QL)):
+                out[f"{dn}_t{t}_Q{i}"] = npy(q)
+                out[f"{dn}_t{t}_L{i}"] = npy(ell)
+    save("kroneq_" + name, out)
+
+
+def gen_kron_eq():
+    all3 = ("fp64", "fp32", "bf16")
+    gen_kron_eq_case("scalar", (), all3, T=4, seed=51)
+    gen_kron_eq_case("vec33", (33,), all3, T=4, seed=52)
+    gen_kron_eq_case("m48x32", (48, 32), all3, T=8, seed=53)                      # [diag, dense]
+    gen_kron_eq_case("m32x48", (32, 48), all3, T=6, seed=54)                      # [dense, diag]
+    gen_kron_eq_case("m64x64", (64, 64), all3, T=8, seed=55, force_balance_at=3)  # [dense, dense] + balance branch
+    gen_kron_eq_case("m24x40_diagdiag", (24, 40), all3, T=4, max_skew=0.0, seed=57)
+    gen_kron_eq_case("m150x200", (150, 200), ("fp32", "bf16"), T=4, seed=58)      # several 64-blocks per triangular solve
+    gen_kron_eq_case("m257x120", (257, 120), ("fp32", "bf16"), T=3, max_skew=float("inf"), seed=59)
+    gen_kron_eq_case("t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=60)          # oracle only: N-D under EQ is not built
+
+
 # ------------------------------------------------------------------------------------------------
 # C. KWNS4.step (the torch.optim shell the build mirrors)
 # ------------------------------------------------------------------------------------------------
@@ -423,5 +470,6 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     gen_helpers()
     gen_kron()
+    gen_kron_eq()
     gen_kwns4()
     gen_lra()

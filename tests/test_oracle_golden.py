@@ -16,6 +16,7 @@ TOL = {"fp64": 1e-10, "fp32": 5e-6, "bf16": 4e-2}
 
 def test_golden_fixtures_present():
     assert len(golden_names("kron_")) >= 20
+    assert len(golden_names("kroneq_")) >= 8
     assert len(golden_names("kwns4_")) >= 6
     assert len(golden_names("lra_")) >= 3
     assert len(golden_names("lrawhiten_")) >= 2
@@ -58,6 +59,29 @@ def test_kron_update_and_apply(name):
                 assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= TOL[dn], (name, dn, t, i, "Q")
                 assert relerr(ell, z[f"{dn}_t{t}_L{i}"]) <= TOL[dn], (name, dn, t, i, "L")
                 assert ell.dtype == (torch.float64 if dn == "fp64" else torch.float32)
+
+
+@pytest.mark.parametrize("name", golden_names("kroneq_"))
+def test_kron_eq_update_and_apply(name):
+    """The triangular geometry dQ = E*Q (psgd.py:278-336) against the reference's own outputs."""
+    z = load(name)
+    Tn = int(z["T"])
+    for dn in kron_dtypes(z):
+        dt = DT[dn]
+        QL, kinds = orc.init_kron(T(z["G0"], dt), Scale=float(z["Scale"]), max_size=float(z["max_size"]),
+                                  max_skew=float(z["max_skew"]))
+        for t in range(Tn):
+            G = T(z[f"G{t}"], dt)
+            noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            orc.update_precond_kron_whiten_eq(QL, G, noise, lr=float(z["lr"]), betaL=float(z["betaL"]),
+                                              damping=float(z["damping"]))
+            h = orc.precond_grad_kron(QL[0], G)
+            assert relerr(h, z[f"{dn}_t{t}_h"]) <= TOL[dn], (name, dn, t, "h")
+            for i, (q, ell) in enumerate(zip(*QL)):
+                assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= TOL[dn], (name, dn, t, i, "Q")
+                assert relerr(ell, z[f"{dn}_t{t}_L{i}"]) <= TOL[dn], (name, dn, t, i, "L")
+                if q.dim() == 2:
+                    assert float(torch.tril(q, -1).abs().max()) == 0.0        # Q stays upper triangular
 
 
 def _kw_from_golden(z):
