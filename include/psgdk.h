@@ -67,6 +67,13 @@ int psgdk_plan_destroy(psgdk_plan* plan);
  * the tensor's index in the plan).  New relative to the reference, which keeps replicas in lock-step by broadcasting
  * torch RNG state (wrapped_as_torch_optimizer_for_ddp.py:88-104). */
 int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
+/* Optional, before psgdk_plan_arena_bytes / psgdk_plan_bind: the update geometry the plan will be driven with -- the dQ
+ * argument of psgd.init_kron (psgd.py:161).  PSGDK_GEOM_Q0P5EQ1P5 (default; dense Q, psgd.py:394-419) or PSGDK_GEOM_EQ
+ * (upper-triangular Q, psgd.py:278-336; needs extra work buffers; tensors with more than 2 dims ->
+ * PSGDK_ERR_UNSUPPORTED).  The other geometries of the reference (QEP, QEQ, QUAD, QUAD4P, PRO4P) are not built. */
+#define PSGDK_GEOM_Q0P5EQ1P5 0
+#define PSGDK_GEOM_EQ 1
+int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
 int psgdk_plan_arena_bytes(const psgdk_plan* plan, size_t* state_bytes, size_t* work_bytes);
@@ -126,6 +133,17 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
                                    const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                                    const uint8_t* balance_mask, void* stream);
 
+/* ---- replaces psgd.update_precond_kron_whiten_eq -> update_precond_kron_eq (psgd.py:330-336 -> 278-319), the
+ * triangular geometry dQ = E*Q:  V = noise, Hvp = G + (damping + eps|G|) V;  A = (kron Q) Hvp (exprA);
+ * B = V x_i Q_i^{-T} by right triangular solves carried out in fp32 (psgd.py:288-303);  per factor
+ * term1 = Gram_i(A), term2 = Gram_i(B);  dense: ell = ||term1+term2||_lb (psgd.py:46-68), Q -= lr/L triu(term1-term2) Q;
+ * diagonal: ell = max(term1+term2), q -= lr/L (term1-term2) q;  then the 1% balancing (psgd.py:318-319).
+ * The plan must have been created with psgdk_plan_set_geometry(plan, PSGDK_GEOM_EQ) (else PSGDK_ERR_STATE).
+ * noise->g_noise is V (probe AND damping noise, psgd.py:334-336); noise->spd_noise as above; skh_noise is not read. */
+int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                            const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                            const uint8_t* balance_mask, void* stream);
+
 /* ---- replaces psgd.precond_grad_kron (psgd.py:322-327): h_t = (kron_i Q_i^T Q_i) src_t for every tensor; h stays
  * in the work arena (consumed by psgdk_apply_update / psgdk_read_precond_grad). */
 int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream);
@@ -175,6 +193,12 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
 /* times `iters` launches of a batch of identical dense problems (contiguous operands) with hipEvents: avg ms/launch */
 int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
                           int symmetric, int iters, float* avg_ms, void* stream);
+
+/* X = Y * inv(U) for an upper-triangular U [d x d, row stride ld_u] and Y [rows x d, row stride ld] (the fp32 right
+ * solve of psgd.py:288-293), same kernel the EQ update uses; dp = roundup(d, 64) must equal ld_u and ld, buffers padded
+ * with zeros to multiples of 64 in both extents.  out_nat [rows_p x dp] and/or out_t [dp x rows_p] (either may be NULL). */
+int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d,
+                          void* stream);
 
 #ifdef __cplusplus
 }

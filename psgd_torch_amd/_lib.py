@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE = 0, 1, 2, 3, 4
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
+GEOM_Q0P5EQ1P5, GEOM_EQ = 0, 1
 SRC_EMA, SRC_GRAD = 0, 1
 
 
@@ -39,6 +40,7 @@ SIGNATURES = {
                                     C.c_double, C.c_double, C.c_int, C.c_int]),
     "psgdk_plan_destroy": (C.c_int, [C.c_void_p]),
     "psgdk_plan_set_stream_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "psgdk_plan_set_geometry": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_plan_arena_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "psgdk_plan_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "psgdk_plan_num_factors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "psgdk_update_precond_q0p5eq1p5": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                                  C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8),
                                                  C.c_void_p]),
+    "psgdk_update_precond_eq": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.c_void_p]),
     "psgdk_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_apply_update": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_void_p]),
@@ -72,6 +76,8 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "psgdk_test_trsm_right": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
 }
 
 

@@ -9,6 +9,7 @@
 #include "kernels_dense.hiph"
 #include "kernels_lra.hiph"
 #include "kernels_gen.hiph"
+#include "kernels_eq.hiph"
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -51,6 +52,7 @@ struct psgdk_plan {
     std::vector<unsigned> tile_begin;                // per tensor range in d_tiles_all
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
+    std::vector<const void*> h_noise_a, h_noise_b;          // staging for explicit-noise pointer tables
     std::vector<const void*> h_ptr_a, h_ptr_b;              // what the device tables currently hold (uploads are skipped
                                                             // when a call passes the same addresses as the previous one)
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
@@ -61,6 +63,14 @@ struct psgdk_plan {
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
+    // PSGDK_GEOM_EQ (psgd.py:278-336): A = (kron Q) Hvp in two products, Grams of A and B, Q -= mu triu(.) Q; the right
+    // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
+    int geometry = PSGDK_GEOM_Q0P5EQ1P5;
+    Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
+    std::vector<int> e_gram_prob;                    // per dense factor: index into e_g1 / e_g2
+    TrsmJob* d_trsm[2] = {nullptr, nullptr}; TrsmTile* d_trsm_tiles[2] = {nullptr, nullptr};
+    unsigned n_trsm_tiles[2] = {0, 0};
+    UinvJob* d_uinv = nullptr; unsigned n_uinv = 0;
     // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -69,6 +79,7 @@ struct psgdk_plan {
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
         for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
+        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd}) v.push_back(e);
         return v;
     }
 
@@ -78,6 +89,8 @@ struct psgdk_plan {
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
+        for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
+        fr(d_uinv);
     }
 };
 
@@ -154,6 +167,74 @@ static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T
     return cur;
 }
 
+// arena layout (offsets in the descriptors); depends on the geometry, so psgdk_plan_set_geometry redoes it
+static void layout_arenas(psgdk_plan* P) {
+    const size_t esz = P->esz;
+    const int n_tensors = P->n_tensors;
+    // ---- state arena: [L fp32 per factor][diag vectors][Q, Qt][ema] ----
+    size_t so = 0;
+    for (auto& G : P->dd) { G.L_off = so; so += 4; }
+    for (auto& F : P->dn) { F.L_off = so; so += 4; }
+    so = align256(so);
+    for (auto& G : P->dd) { G.a_off = so; so += align256((size_t)round_up64(G.len) * esz); }
+    for (auto& F : P->dn) {
+        const size_t mb = align256((size_t)F.dp * F.dp * esz);
+        F.q_off = so; so += mb; F.qt_off = so; so += mb;
+    }
+    for (auto& D : P->td) {
+        D.ema_off = so;
+        if (P->use_momentum) so += align256((size_t)D.Rp * D.Cp * esz);
+    }
+    P->state_bytes = align256(so);
+    // ---- work arena ----
+    size_t wo = 0;
+    P->zero_off = wo;
+    for (auto& F : P->dn) { F.sc_off = wo; wo += 64; }
+    wo = align256(wo);
+    for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * 64 * 4; }
+    wo = align256(wo);
+    for (auto& F : P->dn) { F.rowss_off = wo; wo += align256((size_t)F.dp * 4); }
+    for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
+    if (P->geometry == PSGDK_GEOM_EQ)
+        for (auto& G : P->dd) { G.sum2_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
+    P->zero_bytes = wo - P->zero_off;
+    P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
+    P->diag_mu_off = wo; wo += align256((P->dd.size() + 1) * 4);
+    for (auto& G : P->dd) P->max_diag_len = std::max(P->max_diag_len, G.len);
+    for (auto& D : P->td) {
+        const size_t mb = align256((size_t)D.Rp * D.Cp * esz);
+        D.gc_off = wo; wo += mb; D.x_off = wo; wo += mb; D.h_off = wo; wo += mb;
+        if (D.kind == TK_M1 || D.kind == TK_M2) { D.pgt_off = wo; wo += mb; }
+        if (D.kind == TK_M2) { D.pg_off = wo; wo += mb; D.tt_off = wo; wo += mb; }
+        if (P->geometry == PSGDK_GEOM_EQ) {
+            D.v_off = wo; wo += mb;
+            if (D.kind == TK_M1 || D.kind == TK_M2) { D.bt_off = wo; wo += mb; }
+            if (D.kind == TK_M2) { D.bb_off = wo; wo += mb; }
+        }
+    }
+    for (auto& F : P->dn) {
+        const size_t mb = align256((size_t)F.dp * F.dp * esz);
+        size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off};
+        for (size_t* o : offs) { *o = wo; wo += mb; }
+        F.va_off = wo; wo += align256((size_t)64 * F.dp * esz);
+        F.vb_off = wo; wo += align256((size_t)64 * F.dp * esz);
+        // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
+        const TensorDesc& D = P->td[F.tensor];
+        const int K = F.is_row ? D.Cp : D.Rp;
+        F.slab_off = 0;
+        if (P->geometry == PSGDK_GEOM_EQ) { F.uinv_off = wo; wo += align256((size_t)F.dp * 64 * 4); }
+        if (D.kind != TK_GEN && K > 4096) {
+            const int nks = (K + 3071) / 3072;
+            F.slab_off = wo; wo += align256((size_t)nks * F.dp * F.dp * 4);
+        }
+    }
+    for (auto& g : P->gd) {
+        const size_t nb = align256((size_t)P->td[g.tensor].numel * esz);
+        g.pp_off[0] = wo; wo += nb; g.pp_off[1] = wo; wo += nb;
+    }
+    P->work_bytes = align256(wo);
+}
+
 bool is_dense_dim(int64_t size, int64_t numel, double max_size, double max_skew) {
     // psgd.py:208  -- diagonal iff size <= 1 or size > max_size or size**2 > max_skew * numel
     return !(size <= 1 || (double)size > max_size || (double)size * (double)size > max_skew * (double)numel);
@@ -186,7 +267,6 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->n_tensors = n_tensors; P->dtype = precond_dtype; P->use_momentum = use_momentum ? 1 : 0;
     P->esz = precond_dtype == PSGDK_BF16 ? 2 : 4;
     P->max_size = max_size; P->max_skew = max_skew;
-    const size_t esz = P->esz;
     size_t dpos = 0;
     // ---- structure (init_kron's dense/diag rule) ----
     for (int t = 0; t < n_tensors; ++t) {
@@ -279,60 +359,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
             }
         }
     }
-    // ---- state arena: [L fp32 per factor][diag vectors][Q, Qt][ema] ----
-    size_t so = 0;
-    for (auto& G : P->dd) { G.L_off = so; so += 4; }
-    for (auto& F : P->dn) { F.L_off = so; so += 4; }
-    so = align256(so);
-    for (auto& G : P->dd) { G.a_off = so; so += align256((size_t)round_up64(G.len) * esz); }
-    for (auto& F : P->dn) {
-        const size_t mb = align256((size_t)F.dp * F.dp * esz);
-        F.q_off = so; so += mb; F.qt_off = so; so += mb;
-    }
-    for (auto& D : P->td) {
-        D.ema_off = so;
-        if (P->use_momentum) so += align256((size_t)D.Rp * D.Cp * esz);
-    }
-    P->state_bytes = align256(so);
-    // ---- work arena ----
-    size_t wo = 0;
-    P->zero_off = wo;
-    for (auto& F : P->dn) { F.sc_off = wo; wo += 64; }
-    wo = align256(wo);
-    for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * 64 * 4; }
-    wo = align256(wo);
-    for (auto& F : P->dn) { F.rowss_off = wo; wo += align256((size_t)F.dp * 4); }
-    for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
-    P->zero_bytes = wo - P->zero_off;
-    P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
-    P->diag_mu_off = wo; wo += align256((P->dd.size() + 1) * 4);
-    for (auto& G : P->dd) P->max_diag_len = std::max(P->max_diag_len, G.len);
-    for (auto& D : P->td) {
-        const size_t mb = align256((size_t)D.Rp * D.Cp * esz);
-        D.gc_off = wo; wo += mb; D.x_off = wo; wo += mb; D.h_off = wo; wo += mb;
-        if (D.kind == TK_M1 || D.kind == TK_M2) { D.pgt_off = wo; wo += mb; }
-        if (D.kind == TK_M2) { D.pg_off = wo; wo += mb; D.tt_off = wo; wo += mb; }
-    }
-    for (auto& F : P->dn) {
-        const size_t mb = align256((size_t)F.dp * F.dp * esz);
-        size_t* offs[] = {&F.p_off, &F.t1_off, &F.qn_off, &F.qtn_off, &F.r_off, &F.rq_off, &F.rqt_off};
-        for (size_t* o : offs) { *o = wo; wo += mb; }
-        F.va_off = wo; wo += align256((size_t)64 * F.dp * esz);
-        F.vb_off = wo; wo += align256((size_t)64 * F.dp * esz);
-        // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
-        const TensorDesc& D = P->td[F.tensor];
-        const int K = F.is_row ? D.Cp : D.Rp;
-        F.slab_off = 0;
-        if (D.kind != TK_GEN && K > 4096) {
-            const int nks = (K + 3071) / 3072;
-            F.slab_off = wo; wo += align256((size_t)nks * F.dp * F.dp * 4);
-        }
-    }
-    for (auto& g : P->gd) {
-        const size_t nb = align256((size_t)P->td[g.tensor].numel * esz);
-        g.pp_off[0] = wo; wo += nb; g.pp_off[1] = wo; wo += nb;
-    }
-    P->work_bytes = align256(wo);
+    layout_arenas(P.get());
     *out = P.release();
     return PSGDK_OK;
 }
@@ -346,6 +373,15 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
     }
     for (size_t f = 0; f < plan->dn.size(); ++f)
         plan->dn[f].stream_id = 0x40000000u + (ids[plan->dn[f].tensor] * PSGDK_GEN_MAXDIM + (unsigned)plan->dense_dim[f]) * 2u;
+    return PSGDK_OK;
+}
+
+int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
+    if (!plan || (geometry != PSGDK_GEOM_Q0P5EQ1P5 && geometry != PSGDK_GEOM_EQ)) return PSGDK_ERR_INVALID;
+    if (plan->state) return PSGDK_ERR_STATE;
+    if (geometry == PSGDK_GEOM_EQ && !plan->gd.empty()) return PSGDK_ERR_UNSUPPORTED;   // N-D tensors: Q0.5EQ1.5 only
+    plan->geometry = geometry;
+    layout_arenas(plan);
     return PSGDK_OK;
 }
 
@@ -544,6 +580,77 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->g_app_b.probs.push_back(ab);
         }
     }
+    if (P->geometry == PSGDK_GEOM_EQ) {
+        // ---- triangular geometry (psgd.py:278-336) ----
+        P->e_gram_prob.assign(P->dn.size(), -1);
+        std::vector<TrsmJob> jobs[2]; std::vector<TrsmTile> ttiles[2]; std::vector<UinvJob> uj;
+        for (size_t f = 0; f < P->dn.size(); ++f) {
+            const DenseDesc& F = P->dn[f];
+            const TensorDesc& D = P->td[F.tensor];
+            float* sc = (float*)(W + F.sc_off);
+            uj.push_back(UinvJob{S + F.q_off, (float*)(W + F.uinv_off), F.d, F.dp});
+            // term1 = Gram_i(A) from A / A^T, term2 = Gram_i(B) from B / B^T (psgd.py:306-307)
+            const int K = F.is_row ? D.Cp : D.Rp;
+            GemmProblem g{};
+            g.M = g.N = F.dp; g.K = K; g.lda = g.ldb = K; g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
+            if (F.slab_off) { g.flags |= GF_SPLITK; g.kchunk = 3072; g.slab = (float*)(W + F.slab_off); }
+            P->e_gram_prob[f] = (int)P->e_g1.probs.size();
+            GemmProblem g1 = g; g1.A = g1.B = W + (F.is_row ? D.pg_off : D.pgt_off); g1.C = g1.Ct = W + F.t1_off;
+            GemmProblem g2 = g; g2.A = g2.B = W + (F.is_row ? D.bb_off : D.bt_off); g2.C = g2.Ct = W + F.rq_off;
+            P->e_g1.probs.push_back(g1); P->e_g2.probs.push_back(g2);
+            // Q' = Q - mu triu(term1 - term2) Q  (psgd.py:316)
+            GemmProblem q{};
+            q.A = W + F.r_off; q.B = S + F.qt_off; q.C = W + F.qn_off; q.Ct = W + F.qtn_off;
+            q.M = q.N = q.K = F.dp; q.lda = q.ldb = q.ldc = q.ldct = q.ldq = F.dp; q.alpha = 1.f;
+            q.flags = GF_QUPD; q.Qold = S + F.q_off; q.mu_dev = sc + DS_MU; q.c = 0.f;
+            P->e_qupd.probs.push_back(q);
+        }
+        for (int t = 0; t < P->n_tensors; ++t) {
+            const TensorDesc& D = P->td[t];
+            if (D.kind != TK_M1 && D.kind != TK_M2) continue;
+            const DenseDesc& Fc = P->dn[D.col_dense];
+            const DiagDesc* Gr = D.row_diag >= 0 ? &P->dd[D.row_diag] : nullptr;
+            // A = (row factor) Hvp Qc^T: first the column side
+            GemmProblem a{};
+            a.A = W + D.x_off; a.B = S + Fc.q_off; a.M = D.Rp; a.N = D.Cp; a.K = D.Cp; a.lda = D.Cp; a.ldb = Fc.dp; a.alpha = 1.f;
+            a.flags = GF_TMAJOR; a.ldct = D.Rp;
+            TrsmJob j{};
+            j.in = W + D.v_off; j.ld_in = D.Cp; j.U = S + Fc.q_off; j.uinv = (const float*)(W + Fc.uinv_off);
+            j.rows = D.R; j.dp = Fc.dp;
+            if (D.kind == TK_M1) {
+                a.Ct = W + D.pgt_off;
+                if (Gr) { a.row_scale = S + Gr->a_off; a.row_sumsq = (float*)(W + Gr->sum_off); }
+                j.row_div = Gr ? (const void*)(S + Gr->a_off) : nullptr;
+                j.out_t = W + D.bt_off; j.ld_t = D.Rp;
+                j.row_ss = Gr ? (float*)(W + Gr->sum2_off) : nullptr;
+            } else {
+                const DenseDesc& Fr = P->dn[D.row_dense];
+                a.Ct = W + D.tt_off;
+                GemmProblem b{};
+                b.A = S + Fr.q_off; b.B = W + D.tt_off; b.M = D.Rp; b.N = D.Cp; b.K = D.Rp; b.lda = Fr.dp; b.ldb = D.Rp; b.alpha = 1.f;
+                b.C = W + D.pg_off; b.ldc = D.Cp; b.Ct = W + D.pgt_off; b.ldct = D.Rp;
+                P->e_a2.probs.push_back(b);
+                // V Qc^{-1} -> (.)^T in tt (free again after the second product), then (.)^T Qr^{-1} = B^T, and B
+                j.out_t = W + D.tt_off; j.ld_t = D.Rp;
+                TrsmJob k{};
+                k.in = W + D.tt_off; k.ld_in = D.Rp; k.U = S + Fr.q_off; k.uinv = (const float*)(W + Fr.uinv_off);
+                k.rows = D.C; k.dp = Fr.dp;
+                k.out_nat = W + D.bt_off; k.ld_nat = D.Rp; k.out_t = W + D.bb_off; k.ld_t = D.Cp;
+                for (int pnl = 0; pnl < D.Cp / 64; ++pnl) ttiles[1].push_back(TrsmTile{(int)jobs[1].size(), pnl});
+                jobs[1].push_back(k);
+            }
+            P->e_a1.probs.push_back(a);
+            for (int pnl = 0; pnl < D.Rp / 64; ++pnl) ttiles[0].push_back(TrsmTile{(int)jobs[0].size(), pnl});
+            jobs[0].push_back(j);
+        }
+        for (int k = 0; k < 2; ++k) {
+            P->n_trsm_tiles[k] = (unsigned)ttiles[k].size();
+            if ((rc = upload(&P->d_trsm[k], jobs[k]))) return rc;
+            if ((rc = upload(&P->d_trsm_tiles[k], ttiles[k]))) return rc;
+        }
+        P->n_uinv = (unsigned)uj.size();
+        if ((rc = upload(&P->d_uinv, uj))) return rc;
+    }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
     return PSGDK_OK;
@@ -578,6 +685,27 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream) {
         HIPCHK(hipGetLastError());
     }
     plan->p_valid = false;
+    return PSGDK_OK;
+}
+
+// balancing (psgd.py:266-275, drawn at psgd.py:318 / 418)
+static int run_balance(psgdk_plan* P, const uint8_t* balance_mask, hipStream_t st) {
+    if (balance_mask) {
+        std::vector<int> which;
+        for (int t = 0; t < P->n_tensors; ++t)
+            if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN) which.push_back(t);
+        for (size_t gi = 0; gi < P->gd.size(); ++gi)
+            if (balance_mask[P->gd[gi].tensor])
+                DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
+        if (!which.empty()) {
+            HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(P->d_balnorm, 0, 2 * which.size() * sizeof(float), st));
+            const dim3 bg(64, (unsigned)(2 * which.size()));
+            for (int phase = 0; phase < 2; ++phase)
+                DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, bg, dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
+                                                 P->d_balance, P->state, P->d_balnorm, phase));
+        }
+    }
     return PSGDK_OK;
 }
 
@@ -653,7 +781,8 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
     if (noise) {
         HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
         if (F) {
-            std::vector<const void*> a(F), b(F);
+            std::vector<const void*>& a = P->h_noise_a; std::vector<const void*>& b = P->h_noise_b;
+            a.resize(F); b.resize(F);
             for (unsigned f = 0; f < F; ++f) {
                 const int slot = P->dn[f].tensor * PSGDK_GEN_MAXDIM + P->dense_dim[f];
                 a[f] = noise->spd_noise[slot]; b[f] = noise->skh_noise[slot];
@@ -719,14 +848,14 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
         for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL, 1));
         // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
         launch_stage(P, P->g_qupd, st);
         // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
         DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
         for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL));
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1));
         launch_stage(P, P->g_rq, st);
         launch_stage(P, P->g_rrq, st);
     }
@@ -740,23 +869,86 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
                                          P->state, P->work, mu, 1, lr, betaL));
     }
-    // balancing (psgd.py:418-419)
-    if (balance_mask) {
-        std::vector<int> which;
-        for (int t = 0; t < P->n_tensors; ++t)
-            if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN) which.push_back(t);
-        for (size_t gi = 0; gi < P->gd.size(); ++gi)
-            if (balance_mask[P->gd[gi].tensor])
-                DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
-        if (!which.empty()) {
-            HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemsetAsync(P->d_balnorm, 0, 2 * which.size() * sizeof(float), st));
-            const dim3 bg(64, (unsigned)(2 * which.size()));
-            for (int phase = 0; phase < 2; ++phase)
-                DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, bg, dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
-                                                 P->d_balance, P->state, P->d_balnorm, phase));
+    if ((rc = run_balance(P, balance_mask, st))) return rc;
+    HIPCHK(hipGetLastError());
+    P->p_valid = false;
+    return PSGDK_OK;
+}
+
+int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                            const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                            const uint8_t* balance_mask, void* stream) {
+    if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
+    if (!plan->state || plan->geometry != PSGDK_GEOM_EQ) return PSGDK_ERR_STATE;
+    if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+    if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
+    if (noise && (!noise->g_noise || (!plan->dn.empty() && !noise->spd_noise))) return PSGDK_ERR_INVALID;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned F = (unsigned)P->dn.size();
+    if (noise) {
+        HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+        if (F) {
+            P->h_noise_a.resize(F);
+            for (unsigned f = 0; f < F; ++f) {
+                P->h_noise_a[f] = noise->spd_noise[P->dn[f].tensor * PSGDK_GEN_MAXDIM + P->dense_dim[f]];
+                if (!P->h_noise_a[f]) return PSGDK_ERR_INVALID;
+            }
+            HIPCHK(hipMemcpyAsync(P->d_noise_spd, P->h_noise_a.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
         }
     }
+    const void* const* ng = noise ? (const void* const*)P->d_noise_g : nullptr;
+    const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
+    HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    P->x_valid = false;
+    // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336)
+    DISPATCH_T(P, hipLaunchKernelGGL(eq_make_xv_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
+                                     P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
+    // A = (kron Q) Hvp (psgd.py:295) and B = V x_i Q_i^{-T} (psgd.py:297-303)
+    launch_stage(P, P->e_a1, st);
+    launch_stage(P, P->e_a2, st);
+    if (P->n_uinv)
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_uinv_kernel<T>, dim3((unsigned)(P->max_dp / 64), P->n_uinv), dim3(64), 0, st, P->d_uinv));
+    for (int k = 0; k < 2; ++k)
+        if (P->n_trsm_tiles[k])
+            DISPATCH_T(P, hipLaunchKernelGGL(eq_trsm_kernel<T>, dim3(P->n_trsm_tiles[k]), dim3(256), 0, st, P->d_trsm[k], P->d_trsm_tiles[k]));
+    if (P->n_tiles_diag)
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
+                                         P->d_tiles_diag, P->state, P->work));
+    if (F) {
+        // term1, term2 (psgd.py:306-307)
+        for (int which = 0; which < 2; ++which) {
+            Stage& G = which ? P->e_g2 : P->e_g1;
+            launch_stage(P, G, st);
+            for (unsigned f = 0; f < F; ++f) {
+                const GemmProblem& g = G.probs[P->e_gram_prob[f]];
+                if (!(g.flags & GF_SPLITK)) continue;
+                const DenseDesc& D = P->dn[f];
+                const int nks = (g.K + g.kchunk - 1) / g.kchunk;
+                DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((unsigned)((D.dp / 64) * (D.dp / 64 + 1) / 2)), dim3(256), 0,
+                                                 st, (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, (float*)nullptr, (float*)nullptr, D.d));
+            }
+        }
+        const dim3 grows((unsigned)(P->max_dp / 64), F);
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+        // ell = ||term1 + term2||_lb, L, mu (psgd.py:314-315 -> 46-68)
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
+        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL, 0));
+        // Q -= mu triu(term1 - term2) Q (psgd.py:316)
+        launch_stage(P, P->e_qupd, st);
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
+    }
+    if (!P->dd.empty()) {
+        float* mu = (float*)(P->work + P->diag_mu_off);
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
+                                         P->work, mu, 0, lr, betaL));
+        const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
+                                         P->state, P->work, mu, 1, lr, betaL));
+    }
+    int rc;
+    if ((rc = run_balance(P, balance_mask, st))) return rc;
     HIPCHK(hipGetLastError());
     P->p_valid = false;
     return PSGDK_OK;
@@ -912,6 +1104,33 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_tiles) (void)hipFree(s.d_tiles);
     return rc;
+}
+
+int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d, void* stream) {
+    if (!Y || !U || (!out_nat && !out_t) || rows <= 0 || d <= 0 || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int dp = (int)round_up64(d), rp = (int)round_up64(rows);
+    float* uinv = nullptr; UinvJob* dj = nullptr; TrsmJob* tj = nullptr; TrsmTile* tt = nullptr;
+    HIPCHK(hipMalloc((void**)&uinv, (size_t)dp * 64 * 4));
+    std::vector<UinvJob> uj = {UinvJob{U, uinv, d, dp}};
+    TrsmJob j{};
+    j.in = Y; j.ld_in = dp; j.U = U; j.uinv = uinv; j.out_nat = out_nat; j.ld_nat = dp; j.out_t = out_t; j.ld_t = rp; j.rows = rows; j.dp = dp;
+    std::vector<TrsmJob> jobs = {j};
+    std::vector<TrsmTile> tiles;
+    for (int p = 0; p < rp / 64; ++p) tiles.push_back(TrsmTile{0, p});
+    int rc;
+    if ((rc = upload(&dj, uj)) || (rc = upload(&tj, jobs)) || (rc = upload(&tt, tiles))) return rc;
+    if (dtype == PSGDK_BF16) {
+        hipLaunchKernelGGL(eq_uinv_kernel<bf16_t>, dim3(dp / 64, 1), dim3(64), 0, st, dj);
+        hipLaunchKernelGGL(eq_trsm_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
+    } else {
+        hipLaunchKernelGGL(eq_uinv_kernel<float>, dim3(dp / 64, 1), dim3(64), 0, st, dj);
+        hipLaunchKernelGGL(eq_trsm_kernel<float>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(uinv); (void)hipFree(dj); (void)hipFree(tj); (void)hipFree(tt);
+    return PSGDK_OK;
 }
 
 }  // extern "C"

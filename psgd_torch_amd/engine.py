@@ -18,9 +18,16 @@ from . import _lib as L
 class KronEngine:
     def __init__(self, shapes: Sequence[Sequence[int]], device, precond_dtype=torch.bfloat16, max_size=float("inf"),
                  max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0,
-                 tensor_ids: Optional[Sequence[int]] = None):
+                 tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5"):
         """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124).
-        tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices)."""
+        tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices).
+        geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5" (dense Q) or "EQ" (upper-triangular Q)."""
+        if geometry in ("Q0.5EQ1.5", "Q0p5EQ1p5"):
+            self.geometry = L.GEOM_Q0P5EQ1P5
+        elif geometry == "EQ":
+            self.geometry = L.GEOM_EQ
+        else:
+            raise NotImplementedError(f"dQ={geometry!r}: only the Q0.5EQ1.5 and EQ geometries are built")
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -40,6 +47,8 @@ class KronEngine:
             assert len(tensor_ids) == self.n
             ids = (C.c_uint32 * self.n)(*[int(i) for i in tensor_ids])
             L.check(self.lib.psgdk_plan_set_stream_ids(self._plan, ids), "set_stream_ids")
+        if self.geometry != L.GEOM_Q0P5EQ1P5:
+            L.check(self.lib.psgdk_plan_set_geometry(self._plan, self.geometry), "set_geometry")
         sb, wb = C.c_size_t(), C.c_size_t()
         L.check(self.lib.psgdk_plan_arena_bytes(self._plan, C.byref(sb), C.byref(wb)), "arena_bytes")
         with torch.cuda.device(self.device):
@@ -146,7 +155,8 @@ class KronEngine:
 
     def update_precond(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0,
                        noise=None, balance_mask: Optional[Sequence[bool]] = None):
-        """noise: None (Philox) or (g_noise list[n], spd dict{(t,i): tensor}, skh dict{(t,i): tensor})."""
+        """noise: None (Philox) or (g_noise list[n], spd dict{(t,i): tensor}, skh dict{(t,i): tensor}).
+        Dispatches on the plan's geometry: psgd.py:394-419 (Q0.5EQ1.5) or psgd.py:330-336 (EQ; skh is not read)."""
         nz_ptr = None
         keep = []
         if noise is not None:
@@ -166,9 +176,9 @@ class KronEngine:
         bm = None
         if balance_mask is not None:
             bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
-        L.check(self.lib.psgdk_update_precond_q0p5eq1p5(self._plan, int(source), float(lr), float(betaL), float(damping),
-                                                        nz_ptr, int(seed), int(offset), bm, self._stream()),
-                "update_precond")
+        fn = self.lib.psgdk_update_precond_eq if self.geometry == L.GEOM_EQ else self.lib.psgdk_update_precond_q0p5eq1p5
+        L.check(fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed), int(offset), bm,
+                   self._stream()), "update_precond")
         self._keep_noise = keep
 
     def precond_grad(self, source: int):

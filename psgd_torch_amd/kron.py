@@ -2,6 +2,7 @@
 
     init_kron(t, Scale, max_size, max_skew, dQ)                         psgd.py:161
     update_precond_kron_whiten_q0p5eq1p5(QL, exprs, G, lr, betaL, damping)   psgd.py:394
+    update_precond_kron_whiten_eq(QL, exprs, G, lr, betaL, damping)     psgd.py:330   (init_kron(..., dQ="EQ"))
     precond_grad_kron(QL, exprs, G)                                     psgd.py:322
 
 so that the three lines wrapped_as_torch_optimizer_for_ddp.py:84-86 can point here.  `exprs` -- compiled einsum
@@ -16,19 +17,19 @@ import torch
 from . import _lib as L
 from .engine import KronEngine
 
-_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5"}
+_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ"}
 
 
 def init_kron(t: torch.Tensor, Scale=1.0, max_size=float("inf"), max_skew=1.0, dQ="Q0.5EQ1.5"):
     """psgd.py:161-263.  Returns [[Q, L], exprs]; t must live on a ROCm device in bf16 or fp32."""
     if dQ not in _SUPPORTED_DQ:
-        raise NotImplementedError(f"dQ={dQ!r}: only the Q0.5EQ1.5 geometry is built (the one KWNS4 uses)")
+        raise NotImplementedError(f"dQ={dQ!r}: only the Q0.5EQ1.5 (the one KWNS4 uses) and EQ geometries are built")
     if t.dim() > 26:
         raise ValueError(f"Got tensor with dim {t.dim()}; einsum runs out of letters; replace 26 with larger numbers.")
     if torch.is_complex(t):
         raise NotImplementedError("real tensors only (as wrapped_as_torch_optimizer_for_ddp.KWNS4)")
     eng = KronEngine([tuple(t.shape)], t.device, precond_dtype=t.dtype, max_size=max_size, max_skew=max_skew,
-                     use_momentum=False, init_scale=float(Scale))
+                     use_momentum=False, init_scale=float(Scale), geometry=dQ)
     return [eng.QL(0), (eng,)]
 
 
@@ -44,7 +45,23 @@ def update_precond_kron_whiten_q0p5eq1p5(QL, exprs, G, lr=0.1, betaL=0.9, dampin
     Philox (seed, offset) pair and the 1%-balancing gate are drawn from torch's global CPU generator, so
     torch.manual_seed() makes a run reproducible.  `noise` / `balance` override them (parity tests)."""
     eng = _engine(exprs)
+    if eng.geometry != L.GEOM_Q0P5EQ1P5:
+        raise ValueError('QL/exprs must come from init_kron(..., dQ="Q0.5EQ1.5")')
     eng.state_changed()                      # the caller may have written into the Q views
+    eng.accumulate([G.to(eng.dtype).contiguous()], keep_grad=True)
+    seed = int(torch.randint(0, 2 ** 62, ()).item()) if noise is None else 0
+    if balance is None:
+        balance = bool(torch.rand([]) < 0.01)
+    eng.update_precond(L.SRC_GRAD, lr, betaL, damping, seed=seed, offset=0, noise=noise, balance_mask=[balance])
+
+
+def update_precond_kron_whiten_eq(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9, *, noise=None, balance=None):
+    """psgd.py:330-336 -> 278-319 (the triangular geometry; QL/exprs from init_kron(..., dQ="EQ")), in place on QL.
+    noise = (g_noise list, spd dict, {}) overrides the Philox draws; g_noise is the probe V of psgd.py:334."""
+    eng = _engine(exprs)
+    if eng.geometry != L.GEOM_EQ:
+        raise ValueError('QL/exprs must come from init_kron(..., dQ="EQ")')
+    eng.state_changed()
     eng.accumulate([G.to(eng.dtype).contiguous()], keep_grad=True)
     seed = int(torch.randint(0, 2 ** 62, ()).item()) if noise is None else 0
     if balance is None:

@@ -4,7 +4,8 @@ Same constructor arguments, the same MUTABLE attributes the reference's users an
 lr_preconditioner, betaL, damping, momentum, grad_clip_max_amps, preconditioner_update_probability,
 update_preconditioner_first; cf. misc/gpt2.py:440, misc/vit.py:362-363) and the same step(closure) protocol, so that
 scripts such as misc/gpt2.py / misc/vit.py / rnn_xor_problem_general_purpose_preconditioner.py can switch by changing
-the import.  Only the Q0.5EQ1.5 geometry is built (the reference's default and recommended choice, psgd.py:10-12).
+the import.  Built geometries: dQ = "Q0.5EQ1.5" (the reference's default and recommended choice, psgd.py:10-12) and
+dQ = "EQ" (the triangular one, psgd.py:278-336; tensors with at most two non-singleton dims).
 """
 from __future__ import annotations
 
@@ -31,8 +32,9 @@ class KronWhiten:
         self.preconditioner_update_probability = preconditioner_update_probability
         self.update_preconditioner_first = update_preconditioner_first
         # protected members
-        if dQ not in {"Q0.5EQ1.5", "Q0p5EQ1p5"}:
-            raise NotImplementedError(f"dQ={dQ!r}: only the Q0.5EQ1.5 geometry is built")
+        if dQ not in {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ"}:
+            raise NotImplementedError(f"dQ={dQ!r}: only the Q0.5EQ1.5 and EQ geometries are built")
+        self._dQ = dQ
         self._preconditioner_max_size = preconditioner_max_size
         self._preconditioner_max_skew = preconditioner_max_skew
         params_with_grad = [params_with_grad, ] if isinstance(params_with_grad, torch.Tensor) else params_with_grad
@@ -56,7 +58,7 @@ class KronWhiten:
         p0 = self._params_with_grad[0]
         self._engine = KronEngine([tuple(g.shape) for g in grads], p0.device, precond_dtype=grads[0].dtype,
                                   max_size=self._preconditioner_max_size, max_skew=self._preconditioner_max_skew,
-                                  use_momentum=True, init_scale=float(scale))
+                                  use_momentum=True, init_scale=float(scale), geometry=self._dQ)
         self._QLs = [self._engine.QL(k) for k in range(len(grads))]
 
     @torch.no_grad()
@@ -90,7 +92,7 @@ class KronWhiten:
         src_p = L.SRC_EMA if use_m else L.SRC_GRAD
         t = self._step
         damp = None
-        if first or last:
+        if (first or last) and self._dQ != "EQ":          # (the EQ update builds its own (V, Hvp) pair)
             damp = dict(source=src_w, damping=self.damping, seed=self._seed, offset=2 * t + (0 if first else 1))
         if use_m:
             eng.accumulate(grads, beta=beta, keep_grad=(src_w == L.SRC_GRAD), damp=damp)

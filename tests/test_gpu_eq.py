@@ -1,0 +1,147 @@
+"""
+GPU parity tests of the triangular geometry dQ = E*Q (psgd.py:278-336; init_kron(dQ="EQ") + update_precond_kron_whiten_eq)
+through the C ABI.  Same tolerance scheme as test_gpu_kron.py; here Q itself is compared as well (a triangular factor
+has no orthogonal gauge freedom: the reference's Q is reproduced, not only P = Q^T Q).
+"""
+import pytest
+import torch
+
+from helpers import DT, P_of, T, golden_names, kron_dtypes, kron_noise_from_golden, load, relerr
+from oracle import psgd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("dt,code,tol", [(torch.float32, 1, 2e-5), (torch.bfloat16, 0, 2e-2)])
+@pytest.mark.parametrize("rows,d", [(1, 40), (100, 64), (70, 200), (300, 768)])
+def test_trsm_right_kernel(dt, code, tol, rows, d):
+    """X = Y inv(U) (psgd.py:288-293) against torch's fp64 solve."""
+    from psgd_torch_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(rows * 1000 + d)
+    dp, rp = (d + 63) // 64 * 64, (rows + 63) // 64 * 64
+    U = torch.triu(torch.randn(d, d, generator=g) / d ** 0.5) + torch.eye(d) * 1.5
+    Y = torch.randn(rows, d, generator=g)
+    Up = torch.zeros(dp, dp, dtype=dt); Up[:d, :d] = U.to(dt)
+    Yp = torch.zeros(rp, dp, dtype=dt); Yp[:rows, :d] = Y.to(dt)
+    ref = torch.linalg.solve_triangular(Up[:d, :d].double(), Yp[:rows, :d].double(), upper=True, left=False)
+    Ud, Yd = Up.to(DEV), Yp.to(DEV)
+    for use_nat, use_t in [(True, True), (True, False), (False, True)]:
+        On = torch.zeros(rp, dp, dtype=dt, device=DEV) if use_nat else None
+        Ot = torch.zeros(dp, rp, dtype=dt, device=DEV) if use_t else None
+        _lib.check(lib.psgdk_test_trsm_right(Yd.data_ptr(), Ud.data_ptr(), On.data_ptr() if use_nat else None,
+                                             Ot.data_ptr() if use_t else None, code, rows, d, _lib.current_stream()))
+        if use_nat:
+            assert relerr(On[:rows, :d], ref) <= tol, (rows, d, "nat", relerr(On[:rows, :d], ref))
+            assert float(On[rows:].abs().max() if rows < rp else 0) == 0 and float(On[:, d:].abs().max() if d < dp else 0) == 0
+        if use_t:
+            assert relerr(Ot[:d, :rows].t(), ref) <= tol, (rows, d, "t", relerr(Ot[:d, :rows].t(), ref))
+        if use_nat and use_t:
+            assert torch.equal(On, Ot.t())
+
+
+def _noise_to_dev(noise):
+    g = [noise.g_noise.to(DEV)]
+    spd = {(0, i): x.to(DEV) for i, x in enumerate(noise.spd) if x is not None}
+    return (g, spd, {})
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("kroneq_") if "t7x5x3" not in n])
+def test_eq_functional_seam_vs_golden(name):
+    import psgd_torch_amd as amd
+    z = load(name)
+    Tn = int(z["T"])
+    lr, betaL, damping = float(z["lr"]), float(z["betaL"]), float(z["damping"])
+    kw = dict(Scale=float(z["Scale"]), max_size=float(z["max_size"]), max_skew=float(z["max_skew"]))
+    for dn in kron_dtypes(z):
+        if dn == "fp64":
+            continue
+        dt = DT[dn]
+        QL, exprs = amd.init_kron(T(z["G0"], dt).to(DEV), dQ="EQ", **kw)
+        QL64, kinds = orc.init_kron(T(z["G0"], torch.float64), **kw)
+        for t in range(Tn):
+            Gd = T(z[f"G{t}"], dt)
+            noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            amd.update_precond_kron_whiten_eq(QL, exprs, Gd.to(DEV), lr=lr, betaL=betaL, damping=damping,
+                                              noise=_noise_to_dev(noise), balance=noise.balance_u < 0.01)
+            h = amd.precond_grad_kron(QL, exprs, Gd.to(DEV))
+            n64 = orc.KronNoise(noise.g_noise.double(), [x.double() if x is not None else None for x in noise.spd],
+                                [None] * len(noise.spd), noise.balance_u)
+            orc.update_precond_kron_whiten_eq(QL64, Gd.double(), n64, lr=lr, betaL=betaL, damping=damping)
+            h64 = orc.precond_grad_kron(QL64[0], Gd.double())
+            checks = [("h", h, z[f"{dn}_t{t}_h"], h64)]
+            for i in range(len(QL[0])):
+                checks.append((f"Q{i}", QL[0][i], z[f"{dn}_t{t}_Q{i}"], QL64[0][i]))
+                checks.append((f"L{i}", QL[1][i], z[f"{dn}_t{t}_L{i}"], QL64[1][i]))
+                if QL[0][i].dim() == 2:
+                    assert float(torch.tril(QL[0][i], -1).abs().max()) == 0.0, "Q must stay upper triangular"
+            for what, got, gold, truth in checks:
+                if dn == "fp32":
+                    assert relerr(got, gold) <= 3e-5 * (t + 1), (name, dn, t, what, relerr(got, gold))
+                else:
+                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
+                    assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
+
+
+def test_eq_rejects_nd_tensors():
+    import psgd_torch_amd as amd
+    from psgd_torch_amd import _lib
+    with pytest.raises(_lib.PsgdkError) as ei:
+        amd.init_kron(torch.zeros(7, 5, 3, device=DEV), dQ="EQ")
+    assert ei.value.status == _lib.PSGDK_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("shape,max_skew", [((96, 64), 1.0), ((200,), 1.0), ((48, 80), 0.0), ((40, 130), 1.0)])
+def test_eq_known_answer_whitening(shape, max_skew):
+    """misc/psgd_kron_verification.py (whitening branch) with dQ="EQ": G = H1 V H2 with known SPD Kronecker H; after
+    annealed updates with the engine's own Philox noise, precond_grad(G) must recover V."""
+    import psgd_torch_amd as amd
+    torch.manual_seed(3)
+    gen = torch.Generator().manual_seed(5)
+    kinds = orc.kron_factor_kinds(shape, float("inf"), max_skew)
+    Hs = []
+    for s_, kind in zip(shape, kinds):
+        if kind == "dense":
+            W = torch.randn(s_, s_, generator=gen) / s_ ** 0.5
+            Hs.append((torch.eye(s_) * 0.3 + W @ W.t()).to(DEV))
+        else:
+            Hs.append(torch.diag(0.2 + 3 * torch.rand(s_, generator=gen)).to(DEV))
+    QL, exprs = amd.init_kron(torch.zeros(shape, device=DEV), Scale=1.0, max_skew=max_skew, dQ="EQ")
+    num_iters = 2000
+    dgen = torch.Generator(device=DEV).manual_seed(11)
+    for it in range(num_iters):
+        V = torch.randn(shape, device=DEV, generator=dgen)
+        G = Hs[0] @ V if len(shape) == 1 else Hs[0] @ V @ Hs[1]
+        amd.update_precond_kron_whiten_eq(QL, exprs, G, lr=(1 - it / num_iters) / 5, betaL=0.9, damping=0.0)
+    h = amd.precond_grad_kron(QL, exprs, G)
+    err = relerr(h, V)
+    assert err < 0.1, (shape, max_skew, err)
+
+
+def test_kronwhiten_eq_optimises():
+    """KronWhiten(dQ="EQ") (psgd.py:516-654 with the triangular update): an ill-conditioned least-squares problem
+    converges by orders of magnitude."""
+    from psgd_torch_amd import KronWhiten
+    torch.manual_seed(0)
+    shapes = [(24, 40), (40,), (16, 16)]
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    targets = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    scales = [(0.1 + 3 * torch.rand(s, generator=g)).to(DEV) for s in shapes]
+    opt = KronWhiten(ps, preconditioner_init_scale=1.0, whiten_grad=False, lr_params=0.05, lr_preconditioner=0.2,
+                     momentum=0.9, preconditioner_max_skew=2.0, dQ="EQ")
+
+    def loss():
+        return sum((((p - t) * s) ** 2).sum() for p, t, s in zip(ps, targets, scales))
+    l0 = float(loss())
+    for _ in range(300):
+        opt.step(loss)
+    l1 = float(loss())
+    assert l1 < 1e-3 * l0, (l0, l1)
+    for t in range(len(shapes)):
+        for q in opt._QLs[t][0]:
+            if q.dim() == 2:
+                assert float(torch.tril(q, -1).abs().max()) == 0.0
