@@ -111,6 +111,40 @@ def bench_lra(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_eq(args):
+    """The triangular geometry (psgd.py:278-336) on the headline shapes: per step accumulate ->
+    psgdk_update_precond_eq -> precond_grad -> clipped parameter update, driven through KronEngine like KronWhiten does."""
+    from psgd_torch_amd import KronEngine, _lib as L
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    shapes = gpt2_shapes()
+    nparam = sum(math.prod(s) for s in shapes)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    params = [0.02 * torch.randn(*s, device=dev, generator=gen) for s in shapes]
+    grads = [[0.01 * torch.randn(*s, device=dev, generator=gen) for s in shapes] for _ in range(2)]
+    eng = KronEngine(shapes, dev, precond_dtype=torch.bfloat16, max_skew=1.0, use_momentum=True, init_scale=1.0, geometry="EQ")
+
+    def one_step(i):
+        eng.accumulate(grads[i % 2], beta=0.9, keep_grad=False)
+        eng.update_precond(L.SRC_EMA, 0.1, 0.9, 1e-9, seed=1, offset=i, balance_mask=None)
+        eng.precond_grad(L.SRC_EMA)
+        eng.apply_update(params, 2e-4, 0.0, 2.0, 10.0)
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / args.steps
+    out = {"metric": "psgd_kron_step_throughput", "value": nparam / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"GPT-2-small parameter shapes ({nparam} params), dQ=EQ (triangular Q, fp32 right solves), "
+                                  "momentum 0.9, update probability 1, max_skew 1", "preconditioner_dtype": "bf16"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,11 +152,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
-    ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra"],
+    ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
     args = ap.parse_args()
     if args.config == "vit-b-lra":
         return bench_lra(args)
+    if args.config == "gpt2-small-eq":
+        return bench_eq(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
