@@ -12,6 +12,7 @@
 #include "kernels_eq.hiph"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 
 namespace {
@@ -21,7 +22,7 @@ struct Stage {                       // one grouped GEMM launch
     GemmProblem* d_probs = nullptr;
     GemmTile* d_tiles = nullptr;
     unsigned n_tiles = 0;
-    bool big = false;                // 256x128 / 8-wave tiling (gemm_nt_big_kernel)
+    bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_big_kernel)
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -108,6 +109,7 @@ int upload(X** dst, const std::vector<X>& v) {
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
     tb.bm = s.big ? GEMM_BIG_BM : GEMM_BM;
+    tb.bn = s.big ? GEMM_BIG_BN : GEMM_BN;
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
@@ -651,6 +653,19 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         P->n_uinv = (unsigned)uj.size();
         if ((rc = upload(&P->d_uinv, uj))) return rc;
     }
+    // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least two full rounds of its tiles (one
+    // workgroup per CU); below that the 128 x 128 kernel's finer tiles fill the chip better.  The subspace iteration
+    // (M = 64) and the EQ stages stay on the small tiling.  Both tilings accumulate K in the same order: same bits.
+    for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1],
+                     &P->g_app_b}) {
+        int64_t nb = 0;
+        for (const GemmProblem& g : s->probs) {
+            const int64_t tm = (g.M + GEMM_BIG_BM - 1) / GEMM_BIG_BM, tn = (g.N + GEMM_BIG_BN - 1) / GEMM_BIG_BN;
+            const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+            nb += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+        }
+        s->big = nb >= 512;
+    }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
     return PSGDK_OK;
@@ -1052,6 +1067,7 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldct = ldct;
     P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
+    if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
     s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x128 tiling
     s.probs.push_back(P);
     int rc = finish_stage(s);
@@ -1082,6 +1098,7 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
         P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = K; P.ldc = N; P.ldct = M;
         P.alpha = 1.0f; P.flags = (symmetric & 1 ? GF_SYM : 0) | (symmetric & ~1);
         if (symmetric & 1) { P.Ct = P.C; P.ldct = P.ldc; }
+        if (!P.C && P.Ct) P.flags |= GF_TMAJOR;
         s.probs.push_back(P);
     }
     s.big = (symmetric & 1024) != 0;

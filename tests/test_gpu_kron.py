@@ -39,7 +39,7 @@ def test_native_library_loaded():
 @pytest.mark.parametrize("big", [0, 1024])
 @pytest.mark.parametrize("dt,code,tol", [(torch.bfloat16, 0, 2e-2), (torch.float32, 1, 2e-6)])
 def test_gemm_kernel(dt, code, tol, big):
-    """Both tilings of the grouped NT GEMM (128x128 / 4 waves, 256x128 / 8 waves): plain, transposed, symmetric."""
+    """Both tilings of the grouped NT GEMM (128x128 / 4 waves, 256x256 / 8 waves): plain, transposed, symmetric."""
     from psgd_torch_amd import _lib
     lib = _lib.lib()
     st = _lib.current_stream()
@@ -52,6 +52,9 @@ def test_gemm_kernel(dt, code, tol, big):
         _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), B.data_ptr(), Cc.data_ptr(), Ct.data_ptr(), code, M, N, K, K, K, N, M, big, st))
         ref = A.double() @ B.double().t()
         assert relerr(Cc, ref) < tol and relerr(Ct.t(), ref) < tol, (M, N, K)
+        Ct2 = torch.zeros(N, M, device=DEV, dtype=dt)          # transposed output only (the t-major operand order)
+        _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), B.data_ptr(), None, Ct2.data_ptr(), code, M, N, K, K, K, N, M, big, st))
+        assert torch.equal(Ct2, Ct) or relerr(Ct2.t(), ref) < tol, (M, N, K, "t-major")
     for (M, K) in ((128, 64), (192, 256), (768, 2304), (320, 128)):
         A = torch.randn(M, K, device=DEV).to(dt)
         Cc = torch.full((M, M), float("nan"), device=DEV, dtype=dt)

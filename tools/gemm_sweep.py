@@ -23,10 +23,11 @@ run(768, 768, 768, batch=62); run(768, 768, 768, batch=62, mode="CT"); run(768, 
 run(768, 768, 3072, batch=48, sym=1)
 run(4096, 4096, 4096); run(8192, 8192, 8192, iters=5)
 run(16384, 768, 768, dt=torch.float32); run(4096, 4096, 4096, dt=torch.float32, iters=5)
-print("--- big tiling (256x128, 8 waves, 3-stage ring) vs small")
-for shape in ((16384, 768, 768, 1), (16384, 768, 3072, 1), (768, 768, 768, 62), (4096, 4096, 4096, 1)):
+print("--- big tiling (256x256, 8 waves) vs small")
+for shape in ((16384, 768, 768, 1), (50304, 768, 768, 1), (16384, 768, 3072, 1), (768, 768, 768, 62), (1024, 1024, 1024, 48), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1)):
     M, N, K, b = shape
     for flag in (0, 1024):
-        run(M, N, K, batch=b, sym=flag)
+        run(M, N, K, batch=b, sym=flag, iters=5 if M * N * K > 1e11 else 20)
+        run(M, N, K, batch=b, sym=flag | 256, iters=5 if M * N * K > 1e11 else 20)
 run(768, 768, 768, batch=62, mode="CT", sym=1024); run(768, 768, 768, batch=62, sym=1025); run(768, 768, 3072, batch=48, sym=1025)
-run(16384, 768, 768, mode="T", sym=1024); run(8192, 8192, 8192, sym=1024, iters=5)
+run(16384, 768, 768, mode="T", sym=0); run(16384, 768, 768, mode="T", sym=1024); run(768, 768, 768, batch=62, mode="CT", sym=0)
