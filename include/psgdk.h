@@ -70,9 +70,13 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 /* Optional, before psgdk_plan_arena_bytes / psgdk_plan_bind: the update geometry the plan will be driven with -- the dQ
  * argument of psgd.init_kron (psgd.py:161).  PSGDK_GEOM_Q0P5EQ1P5 (default; dense Q, psgd.py:394-419) or PSGDK_GEOM_EQ
  * (upper-triangular Q, psgd.py:278-336; needs extra work buffers; tensors with more than 2 dims ->
- * PSGDK_ERR_UNSUPPORTED).  The other geometries of the reference (QEP, QEQ, QUAD, QUAD4P, PRO4P) are not built. */
+ * PSGDK_ERR_UNSUPPORTED), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483).  The remaining
+ * geometries of the reference (QEP, QUAD4P, PRO4P) are not built.  Each update entry point below requires the plan to
+ * carry its geometry (else PSGDK_ERR_STATE). */
 #define PSGDK_GEOM_Q0P5EQ1P5 0
 #define PSGDK_GEOM_EQ 1
+#define PSGDK_GEOM_QEQ 2
+#define PSGDK_GEOM_QUAD 3
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
@@ -132,6 +136,17 @@ typedef struct psgdk_noise {
 int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping,
                                    const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                                    const uint8_t* balance_mask, void* stream);
+
+/* ---- replace psgd.update_precond_kron_whiten_qeq (psgd.py:367-391: Q -= lr/L (Q term1 - c Q), no Procrustes step) and
+ * psgd.update_precond_kron_whiten_quad (psgd.py:455-483: two half steps p = q - lr/2/L (term1 q - c q),
+ * p = p - lr/2/L (p term1 - c p), q = (p + p^T)/2; diagonal factors q *= (1 - lr/2/L (term1 - c))^2).  Same arguments as
+ * psgdk_update_precond_q0p5eq1p5; noise->skh_noise is not read. */
+int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                             const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                             const uint8_t* balance_mask, void* stream);
+int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                              const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                              const uint8_t* balance_mask, void* stream);
 
 /* ---- replaces psgd.update_precond_kron_whiten_eq -> update_precond_kron_eq (psgd.py:330-336 -> 278-319), the
  * triangular geometry dQ = E*Q:  V = noise, Hvp = G + (damping + eps|G|) V;  A = (kron Q) Hvp (exprA);

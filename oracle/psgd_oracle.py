@@ -226,6 +226,61 @@ def update_precond_kron_whiten_q0p5eq1p5(QL, G: Tensor, noise: KronNoise, lr: fl
     return inter
 
 
+def _whiten_terms(QL, G: Tensor, noise: KronNoise, damping: float):
+    """Shared head of psgd.py:367-392 / 455-483: Pg = (kron Q^T Q)(G + damped noise)."""
+    damp = damping + torch.finfo(G.dtype).eps * G.abs()
+    return precond_grad_kron(QL[0], G + damp * noise.g_noise.to(G.dtype))
+
+
+def update_precond_kron_whiten_qeq(QL, G: Tensor, noise: KronNoise, lr: float = 0.1, betaL: float = 0.9,
+                                   damping: float = 1e-9) -> None:
+    """psgd.py:367-391 (dQ = Q*E*Q), in place on Q and L; noise.skh is unused."""
+    Q, L = QL
+    total_numel = G.numel()
+    Pg = _whiten_terms(QL, G, noise, damping)
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        term1 = gram_mode(Pg, i, dense)
+        if not dense:
+            term2 = total_numel / q.numel()
+            ell = torch.max(term1) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.mul_(1 - lr / L[i] * (term1 - term2))
+        else:
+            term2 = total_numel / q.shape[0]
+            ell = norm_lower_bound_spd(term1, noise.spd[i]) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.sub_(lr / L[i] * (q @ term1 - q * term2))
+    if noise.balance_u < 0.01:
+        balance_kron_precond(Q)
+
+
+def update_precond_kron_whiten_quad(QL, G: Tensor, noise: KronNoise, lr: float = 0.1, betaL: float = 0.9,
+                                    damping: float = 1e-9) -> None:
+    """psgd.py:455-483 (quadratic form; Q stays symmetric), in place on Q and L; noise.skh is unused."""
+    Q, L = QL
+    total_numel = G.numel()
+    Pg = _whiten_terms(QL, G, noise, damping)
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        term1 = gram_mode(Pg, i, dense)
+        if not dense:
+            term2 = total_numel / q.numel()
+            ell = torch.max(term1) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            gain = 1 - lr / 2 / L[i] * (term1 - term2)
+            q.mul_(gain * gain)
+        else:
+            term2 = total_numel / q.shape[0]
+            ell = norm_lower_bound_spd(term1, noise.spd[i]) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            p = q - lr / 2 / L[i] * (term1 @ q - term2 * q)
+            p = p - lr / 2 / L[i] * (p @ term1 - p * term2)
+            q.copy_((p + p.t()) / 2)
+    if noise.balance_u < 0.01:
+        balance_kron_precond(Q)
+
+
 def apply_q_kron(Q: List[Tensor], X: Tensor) -> Tensor:
     """exprA (psgd.py:248-249): A = (kron_i Q_i) X, one factor per mode."""
     if X.dim() == 0:

@@ -68,6 +68,7 @@ struct psgdk_plan {
     // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
+    Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
     std::vector<int> e_gram_prob;                    // per dense factor: index into e_g1 / e_g2
     TrsmJob* d_trsm[2] = {nullptr, nullptr}; TrsmTile* d_trsm_tiles[2] = {nullptr, nullptr};
     unsigned n_trsm_tiles[2] = {0, 0};
@@ -80,7 +81,7 @@ struct psgdk_plan {
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
         for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
-        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd}) v.push_back(e);
+        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2}) v.push_back(e);
         return v;
     }
 
@@ -379,7 +380,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 }
 
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
-    if (!plan || (geometry != PSGDK_GEOM_Q0P5EQ1P5 && geometry != PSGDK_GEOM_EQ)) return PSGDK_ERR_INVALID;
+    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QUAD) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
     if (geometry == PSGDK_GEOM_EQ && !plan->gd.empty()) return PSGDK_ERR_UNSUPPORTED;   // N-D tensors: Q0.5EQ1.5 only
     plan->geometry = geometry;
@@ -582,6 +583,21 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->g_app_b.probs.push_back(ab);
         }
     }
+    if (P->geometry == PSGDK_GEOM_QEQ || P->geometry == PSGDK_GEOM_QUAD)
+        for (size_t f = 0; f < P->dn.size(); ++f) {
+            const DenseDesc& F = P->dn[f];
+            float* sc = (float*)(W + F.sc_off);
+            GemmProblem g{};
+            g.B = W + F.t1_off; g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = g.ldq = F.dp; g.alpha = 1.f;
+            g.flags = GF_QUPD; g.mu_dev = sc + DS_MU; g.c = F.c;
+            if (P->geometry == PSGDK_GEOM_QEQ) {      // Q' = Q - mu (Q term1 - c Q): term1 is symmetric, so it is its own B^T
+                g.A = S + F.q_off; g.Qold = S + F.q_off; g.C = W + F.qn_off; g.Ct = W + F.qtn_off;
+                P->v_qeq.probs.push_back(g);
+            } else {                                   // p2 = p1 - mu/2 (p1 term1 - c p1), p1 = the first half step in qn
+                g.A = W + F.qn_off; g.Qold = W + F.qn_off; g.C = W + F.rq_off; g.Ct = W + F.rqt_off;
+                P->v_quad2.probs.push_back(g);
+            }
+        }
     if (P->geometry == PSGDK_GEOM_EQ) {
         // ---- triangular geometry (psgd.py:278-336) ----
         P->e_gram_prob.assign(P->dn.size(), -1);
@@ -781,14 +797,18 @@ static int ensure_P(psgdk_plan* plan, hipStream_t st) {
     return PSGDK_OK;
 }
 
-int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping,
-                                   const psgdk_noise* noise, uint64_t seed, uint64_t offset,
-                                   const uint8_t* balance_mask, void* stream) {
+// The three geometries that share Pg = (kron Q^T Q)(G + damped noise), the mode Grams and the spectral-norm step
+// normalisation: Q0.5EQ1.5 (psgd.py:394-419), QEQ (psgd.py:367-391), QUAD (psgd.py:455-483).
+static int update_whiten_family(psgdk_plan* plan, int variant, int source, float lr, float betaL, float damping,
+                                const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                                const uint8_t* balance_mask, void* stream) {
     if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
-    if (!plan->state) return PSGDK_ERR_STATE;
+    if (!plan->state || plan->geometry != variant) return PSGDK_ERR_STATE;
     if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
     if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
-    if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || !noise->skh_noise)))) return PSGDK_ERR_INVALID;
+    const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5;
+    if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || (need_skh && !noise->skh_noise))))) return PSGDK_ERR_INVALID;
+    const float lr_eff = variant == PSGDK_GEOM_QUAD ? 0.5f * lr : lr;       // QUAD takes two half steps (psgd.py:473,479-480)
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
@@ -800,8 +820,8 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
             a.resize(F); b.resize(F);
             for (unsigned f = 0; f < F; ++f) {
                 const int slot = P->dn[f].tensor * PSGDK_GEN_MAXDIM + P->dense_dim[f];
-                a[f] = noise->spd_noise[slot]; b[f] = noise->skh_noise[slot];
-                if (!a[f] || !b[f]) return PSGDK_ERR_INVALID;
+                a[f] = noise->spd_noise[slot]; b[f] = need_skh ? noise->skh_noise[slot] : nullptr;
+                if (!a[f] || (need_skh && !b[f])) return PSGDK_ERR_INVALID;
             }
             HIPCHK(hipMemcpyAsync(P->d_noise_spd, a.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(P->d_noise_skh, b.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
@@ -863,31 +883,55 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
         for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL, 1));
-        // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
-        launch_stage(P, P->g_qupd, st);
-        // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
-        DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
-        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1));
-        launch_stage(P, P->g_rq, st);
-        launch_stage(P, P->g_rrq, st);
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr_eff, betaL, 1));
+        if (variant == PSGDK_GEOM_Q0P5EQ1P5) {
+            // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
+            launch_stage(P, P->g_qupd, st);
+            // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
+            DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
+            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1));
+            launch_stage(P, P->g_rq, st);
+            launch_stage(P, P->g_rrq, st);
+        } else if (variant == PSGDK_GEOM_QEQ) {
+            // Q' = Q - mu (Q term1 - c Q) (psgd.py:388), then into the state
+            launch_stage(P, P->v_qeq, st);
+            DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
+        } else {
+            // p = q - mu/2 (term1 q - c q);  p = p - mu/2 (p term1 - c p);  q = (p + p^T)/2  (psgd.py:479-481)
+            launch_stage(P, P->g_qupd, st);
+            launch_stage(P, P->v_quad2, st);
+            DISPATCH_T(P, hipLaunchKernelGGL(quad_symmetrize_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
+        }
     }
     // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
     if (!P->dd.empty())
     {
         float* mu = (float*)(P->work + P->diag_mu_off);
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
-                                         P->work, mu, 0, lr, betaL));
+                                         P->work, mu, 0, lr_eff, betaL, variant == PSGDK_GEOM_QUAD ? 1 : 0));
         const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
-                                         P->state, P->work, mu, 1, lr, betaL));
+                                         P->state, P->work, mu, 1, lr_eff, betaL, variant == PSGDK_GEOM_QUAD ? 1 : 0));
     }
     if ((rc = run_balance(P, balance_mask, st))) return rc;
     HIPCHK(hipGetLastError());
     P->p_valid = false;
     return PSGDK_OK;
+}
+
+int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                                   uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                             uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_QEQ, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                              uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_QUAD, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
 }
 
 int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL, float damping,

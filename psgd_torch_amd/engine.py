@@ -21,13 +21,12 @@ class KronEngine:
                  tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5"):
         """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124).
         tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices).
-        geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5" (dense Q) or "EQ" (upper-triangular Q)."""
-        if geometry in ("Q0.5EQ1.5", "Q0p5EQ1p5"):
-            self.geometry = L.GEOM_Q0P5EQ1P5
-        elif geometry == "EQ":
-            self.geometry = L.GEOM_EQ
-        else:
-            raise NotImplementedError(f"dQ={geometry!r}: only the Q0.5EQ1.5 and EQ geometries are built")
+        geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5", "EQ" (upper-triangular Q), "QEQ", "QUAD"."""
+        codes = {"Q0.5EQ1.5": L.GEOM_Q0P5EQ1P5, "Q0p5EQ1p5": L.GEOM_Q0P5EQ1P5, "EQ": L.GEOM_EQ, "QEQ": L.GEOM_QEQ,
+                 "QUAD": L.GEOM_QUAD}
+        if geometry not in codes:
+            raise NotImplementedError(f"dQ={geometry!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD")
+        self.geometry = codes[geometry]
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -156,7 +155,8 @@ class KronEngine:
     def update_precond(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0,
                        noise=None, balance_mask: Optional[Sequence[bool]] = None):
         """noise: None (Philox) or (g_noise list[n], spd dict{(t,i): tensor}, skh dict{(t,i): tensor}).
-        Dispatches on the plan's geometry: psgd.py:394-419 (Q0.5EQ1.5) or psgd.py:330-336 (EQ; skh is not read)."""
+        Dispatches on the plan's geometry: psgd.py:394-419 (Q0.5EQ1.5), 330-336 (EQ), 367-391 (QEQ), 455-483 (QUAD);
+        only Q0.5EQ1.5 reads skh."""
         nz_ptr = None
         keep = []
         if noise is not None:
@@ -176,7 +176,8 @@ class KronEngine:
         bm = None
         if balance_mask is not None:
             bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
-        fn = self.lib.psgdk_update_precond_eq if self.geometry == L.GEOM_EQ else self.lib.psgdk_update_precond_q0p5eq1p5
+        fn = {L.GEOM_Q0P5EQ1P5: self.lib.psgdk_update_precond_q0p5eq1p5, L.GEOM_EQ: self.lib.psgdk_update_precond_eq,
+              L.GEOM_QEQ: self.lib.psgdk_update_precond_qeq, L.GEOM_QUAD: self.lib.psgdk_update_precond_quad}[self.geometry]
         L.check(fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed), int(offset), bm,
                    self._stream()), "update_precond")
         self._keep_noise = keep

@@ -309,6 +309,53 @@ def gen_kron_eq_case(name, shape, dtypes, T, max_skew=1.0, max_size=float("inf")
     save("kroneq_" + name, out)
 
 
+def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=float("inf"), Scale=1.0, lr=0.3, betaL=0.9,
+                       damping=1e-9, force_balance_at=None, seed=0):
+    """The QEQ / QUAD geometries (psgd.py:367-391, 455-483) behind the same seam."""
+    fn = {"QEQ": psgd.update_precond_kron_whiten_qeq, "QUAD": psgd.update_precond_kron_whiten_quad}[geom]
+    out = {"shape": np.asarray(shape, dtype=np.int64), "T": np.asarray(T), "max_skew": np.asarray(max_skew),
+           "max_size": np.asarray(max_size), "Scale": np.asarray(Scale), "lr": np.asarray(lr),
+           "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
+    G32 = structured_grads(shape, T, seed + 1)
+    for t in range(T):
+        out[f"G{t}"] = npy(G32[t])
+    for dn in dtypes:
+        dt = DT[dn]
+        QL, exprs = psgd.init_kron(G32[0].to(dt), Scale=Scale, max_size=max_size, max_skew=max_skew, dQ=geom)
+        torch.manual_seed(3000 + seed)
+        for t in range(T):
+            G = G32[t].to(dt)
+            ndense = sum(1 for q in QL[0] if q.dim() == 2)
+            force = [0.001 if force_balance_at == t else 0.5]
+            with Recorder(force_rand=force) as r:
+                fn(QL, exprs, G, lr=lr, betaL=betaL, damping=damping)
+            assert len(r.draws) == 1 + ndense + 1, (len(r.draws), ndense)
+            out[f"{dn}_t{t}_gnoise"] = npy(r.draws[0][1])
+            k = 1
+            for i, q in enumerate(QL[0]):
+                if q.dim() == 2:
+                    out[f"{dn}_t{t}_spd{i}"] = npy(r.draws[k][1])
+                    k += 1
+            out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1])
+            out[f"{dn}_t{t}_h"] = npy(psgd.precond_grad_kron(QL, exprs, G))
+            for i, (q, ell) in enumerate(zip(*QL)):
+                out[f"{dn}_t{t}_Q{i}"] = npy(q)
+                out[f"{dn}_t{t}_L{i}"] = npy(ell)
+    save(f"kron{geom.lower()}_" + name, out)
+
+
+def gen_kron_geoms():
+    all3 = ("fp64", "fp32", "bf16")
+    for k, geom in enumerate(("QEQ", "QUAD")):
+        b = 70 + 10 * k
+        gen_kron_geom_case(geom, "vec33", (33,), all3, T=4, seed=b + 1)
+        gen_kron_geom_case(geom, "m48x32", (48, 32), all3, T=8, seed=b + 2)
+        gen_kron_geom_case(geom, "m32x48", (32, 48), all3, T=6, seed=b + 3)
+        gen_kron_geom_case(geom, "m64x64", (64, 64), all3, T=8, seed=b + 4, force_balance_at=3)
+        gen_kron_geom_case(geom, "m150x200", (150, 200), ("fp32", "bf16"), T=3, seed=b + 5)
+        gen_kron_geom_case(geom, "t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=b + 6)
+
+
 def gen_kron_eq():
     all3 = ("fp64", "fp32", "bf16")
     gen_kron_eq_case("scalar", (), all3, T=4, seed=51)
@@ -471,5 +518,6 @@ if __name__ == "__main__":
     gen_helpers()
     gen_kron()
     gen_kron_eq()
+    gen_kron_geoms()
     gen_kwns4()
     gen_lra()

@@ -145,3 +145,46 @@ def test_kronwhiten_eq_optimises():
         for q in opt._QLs[t][0]:
             if q.dim() == 2:
                 assert float(torch.tril(q, -1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_"))
+def test_qeq_quad_functional_seam_vs_golden(name):
+    """dQ = "QEQ" (psgd.py:367-391) and "QUAD" (psgd.py:455-483) through the C ABI vs the reference's outputs; Q itself is
+    compared (neither geometry has the Procrustes gauge step)."""
+    import psgd_torch_amd as amd
+    qeq = name.startswith("kronqeq_")
+    geom = "QEQ" if qeq else "QUAD"
+    upd_amd = amd.update_precond_kron_whiten_qeq if qeq else amd.update_precond_kron_whiten_quad
+    upd_orc = orc.update_precond_kron_whiten_qeq if qeq else orc.update_precond_kron_whiten_quad
+    z = load(name)
+    lr, betaL, damping = float(z["lr"]), float(z["betaL"]), float(z["damping"])
+    kw = dict(Scale=float(z["Scale"]), max_size=float(z["max_size"]), max_skew=float(z["max_skew"]))
+    for dn in kron_dtypes(z):
+        if dn == "fp64":
+            continue
+        dt = DT[dn]
+        QL, exprs = amd.init_kron(T(z["G0"], dt).to(DEV), dQ=geom, **kw)
+        QL64, kinds = orc.init_kron(T(z["G0"], torch.float64), **kw)
+        for t in range(int(z["T"])):
+            Gd = T(z[f"G{t}"], dt)
+            noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            upd_amd(QL, exprs, Gd.to(DEV), lr=lr, betaL=betaL, damping=damping, noise=_noise_to_dev(noise),
+                    balance=noise.balance_u < 0.01)
+            h = amd.precond_grad_kron(QL, exprs, Gd.to(DEV))
+            n64 = orc.KronNoise(noise.g_noise.double(), [x.double() if x is not None else None for x in noise.spd],
+                                [None] * len(noise.spd), noise.balance_u)
+            upd_orc(QL64, Gd.double(), n64, lr=lr, betaL=betaL, damping=damping)
+            h64 = orc.precond_grad_kron(QL64[0], Gd.double())
+            checks = [("h", h, z[f"{dn}_t{t}_h"], h64)]
+            for i in range(len(QL[0])):
+                checks.append((f"Q{i}", QL[0][i], z[f"{dn}_t{t}_Q{i}"], QL64[0][i]))
+                checks.append((f"L{i}", QL[1][i], z[f"{dn}_t{t}_L{i}"], QL64[1][i]))
+                if not qeq and QL[0][i].dim() == 2:
+                    assert torch.equal(QL[0][i], QL[0][i].t()), "QUAD keeps Q symmetric"
+            for what, got, gold, truth in checks:
+                if dn == "fp32":
+                    assert relerr(got, gold) <= 3e-5 * (t + 1), (name, dn, t, what, relerr(got, gold))
+                else:
+                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
+                    assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)

@@ -84,6 +84,26 @@ def test_kron_eq_update_and_apply(name):
                     assert float(torch.tril(q, -1).abs().max()) == 0.0        # Q stays upper triangular
 
 
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_"))
+def test_kron_qeq_quad_update_and_apply(name):
+    """The QEQ / QUAD geometries (psgd.py:367-391, 455-483) against the reference's own outputs."""
+    fn = orc.update_precond_kron_whiten_qeq if name.startswith("kronqeq_") else orc.update_precond_kron_whiten_quad
+    z = load(name)
+    for dn in kron_dtypes(z):
+        dt = DT[dn]
+        QL, kinds = orc.init_kron(T(z["G0"], dt), Scale=float(z["Scale"]), max_size=float(z["max_size"]),
+                                  max_skew=float(z["max_skew"]))
+        for t in range(int(z["T"])):
+            G = T(z[f"G{t}"], dt)
+            noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            fn(QL, G, noise, lr=float(z["lr"]), betaL=float(z["betaL"]), damping=float(z["damping"]))
+            h = orc.precond_grad_kron(QL[0], G)
+            assert relerr(h, z[f"{dn}_t{t}_h"]) <= TOL[dn], (name, dn, t, "h")
+            for i, (q, ell) in enumerate(zip(*QL)):
+                assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= TOL[dn], (name, dn, t, i, "Q")
+                assert relerr(ell, z[f"{dn}_t{t}_L{i}"]) <= TOL[dn], (name, dn, t, i, "L")
+
+
 def _kw_from_golden(z):
     kw = {}
     for k in z.files:
