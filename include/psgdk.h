@@ -70,13 +70,14 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 /* Optional, before psgdk_plan_arena_bytes / psgdk_plan_bind: the update geometry the plan will be driven with -- the dQ
  * argument of psgd.init_kron (psgd.py:161).  PSGDK_GEOM_Q0P5EQ1P5 (default; dense Q, psgd.py:394-419) or PSGDK_GEOM_EQ
  * (upper-triangular Q, psgd.py:278-336; needs extra work buffers; tensors with more than 2 dims ->
- * PSGDK_ERR_UNSUPPORTED), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483).  The remaining
- * geometries of the reference (QEP, QUAD4P, PRO4P) are not built.  Each update entry point below requires the plan to
+ * PSGDK_ERR_UNSUPPORTED), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483), PSGDK_GEOM_QEP
+ * (psgd.py:339-364).  The two geometries of the reference that fit P directly (QUAD4P, PRO4P) are not built.  Each update entry point below requires the plan to
  * carry its geometry (else PSGDK_ERR_STATE). */
 #define PSGDK_GEOM_Q0P5EQ1P5 0
 #define PSGDK_GEOM_EQ 1
 #define PSGDK_GEOM_QEQ 2
 #define PSGDK_GEOM_QUAD 3
+#define PSGDK_GEOM_QEP 4
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
@@ -147,6 +148,11 @@ int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL
 int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping,
                               const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                               const uint8_t* balance_mask, void* stream);
+/* psgd.update_precond_kron_whiten_qep (psgd.py:339-364): balancing of every tensor FIRST and on every call (not optional,
+ * psgd.py:346-347); per factor term1 = Gram_i(Q_i Pg), term2 = (numel/d) Q Q^T, ell = ||term1 + term2||_lb,
+ * Q -= lr/L (term1 - term2) Q (diagonal: q *= 1 - lr/L (term1 - term2)).  No gate draw, hence no balance_mask. */
+int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                             const psgdk_noise* noise, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- replaces psgd.update_precond_kron_whiten_eq -> update_precond_kron_eq (psgd.py:330-336 -> 278-319), the
  * triangular geometry dQ = E*Q:  V = noise, Hvp = G + (damping + eps|G|) V;  A = (kron Q) Hvp (exprA);

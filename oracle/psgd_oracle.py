@@ -281,6 +281,30 @@ def update_precond_kron_whiten_quad(QL, G: Tensor, noise: KronNoise, lr: float =
         balance_kron_precond(Q)
 
 
+def update_precond_kron_whiten_qep(QL, G: Tensor, noise: KronNoise, lr: float = 0.1, betaL: float = 0.9,
+                                   damping: float = 1e-9) -> None:
+    """psgd.py:339-364 (dQ = Q*E*P), in place on Q and L.  Balancing runs on every call, BEFORE the update
+    (psgd.py:346-347); noise.skh and noise.balance_u are unused."""
+    Q, L = QL
+    balance_kron_precond(Q)
+    total_numel = G.numel()
+    Pg = _whiten_terms(QL, G, noise, damping)
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        QPg = (Pg * q if Pg.dim() == 0 else _mode_scale(q, Pg, i)) if not dense else _mode_product(q, Pg, i)   # exprQs[i]
+        term1 = gram_mode(QPg, i, dense)
+        if not dense:
+            term2 = total_numel / q.numel() * q * q
+            ell = torch.max(term1 + term2)
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.mul_(1 - lr / L[i] * (term1 - term2))
+        else:
+            term2 = total_numel / q.shape[0] * q @ q.t()
+            ell = norm_lower_bound_spd(term1 + term2, noise.spd[i])
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.sub_(lr / L[i] * (term1 - term2) @ q)
+
+
 def apply_q_kron(Q: List[Tensor], X: Tensor) -> Tensor:
     """exprA (psgd.py:248-249): A = (kron_i Q_i) X, one factor per mode."""
     if X.dim() == 0:

@@ -5,18 +5,19 @@ Public surface (mirrors the reference's names for this path):
     KronWhiten                                  closure-style shell (psgd.py:516)
     init_kron, update_precond_kron_whiten_q0p5eq1p5, precond_grad_kron      functional seam (psgd.py:161,394,322)
     update_precond_kron_whiten_eq                                           triangular geometry, dQ="EQ" (psgd.py:330)
-    update_precond_kron_whiten_qeq, update_precond_kron_whiten_quad         dQ="QEQ" / "QUAD" (psgd.py:367, 455)
+    update_precond_kron_whiten_qeq, _quad, _qep                             dQ="QEQ" / "QUAD" / "QEP" (psgd.py:367, 455, 339)
     LRAWhiten, update_precond_lra_whiten, precond_grad_lra                  LRA preconditioner (psgd.py:1075,1066,1055)
 Everything computes through libpsgdk.so (hand-written HIP for gfx950, include/psgdk.h); there is no CPU fallback.
 """
 from .kron import (init_kron, precond_grad_kron, update_precond_kron_whiten_eq,  # noqa: F401
-                   update_precond_kron_whiten_q0p5eq1p5, update_precond_kron_whiten_qeq, update_precond_kron_whiten_quad)
+                   update_precond_kron_whiten_q0p5eq1p5, update_precond_kron_whiten_qeq, update_precond_kron_whiten_quad,
+                   update_precond_kron_whiten_qep)
 from .kwns4 import KWNS4  # noqa: F401
 from .engine import KronEngine  # noqa: F401
 from .kron_whiten import KronWhiten  # noqa: F401
 from .lra import LRAWhiten, precond_grad_lra, update_precond_lra_whiten  # noqa: F401
 
 __all__ = ["KWNS4", "KronWhiten", "KronEngine", "init_kron", "update_precond_kron_whiten_q0p5eq1p5", "update_precond_kron_whiten_eq",
-           "update_precond_kron_whiten_qeq", "update_precond_kron_whiten_quad",
+           "update_precond_kron_whiten_qeq", "update_precond_kron_whiten_quad", "update_precond_kron_whiten_qep",
            "precond_grad_kron",
            "LRAWhiten", "update_precond_lra_whiten", "precond_grad_lra"]

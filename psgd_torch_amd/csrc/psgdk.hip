@@ -54,6 +54,7 @@ struct psgdk_plan {
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
     std::vector<const void*> h_noise_a, h_noise_b;          // staging for explicit-noise pointer tables
+    std::vector<int> h_balance;
     std::vector<const void*> h_ptr_a, h_ptr_b;              // what the device tables currently hold (uploads are skipped
                                                             // when a call passes the same addresses as the previous one)
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
@@ -69,6 +70,7 @@ struct psgdk_plan {
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
     Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
+    Stage v_qep_u, v_qep_t1, v_qep_t2;               // PSGDK_GEOM_QEP: Q term1, (Q term1) Q^T, c Q Q^T
     std::vector<int> e_gram_prob;                    // per dense factor: index into e_g1 / e_g2
     TrsmJob* d_trsm[2] = {nullptr, nullptr}; TrsmTile* d_trsm_tiles[2] = {nullptr, nullptr};
     unsigned n_trsm_tiles[2] = {0, 0};
@@ -81,7 +83,7 @@ struct psgdk_plan {
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
         for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
-        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2}) v.push_back(e);
+        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2, &v_qep_u, &v_qep_t1, &v_qep_t2}) v.push_back(e);
         return v;
     }
 
@@ -380,7 +382,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 }
 
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
-    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QUAD) return PSGDK_ERR_INVALID;
+    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QEP) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
     if (geometry == PSGDK_GEOM_EQ && !plan->gd.empty()) return PSGDK_ERR_UNSUPPORTED;   // N-D tensors: Q0.5EQ1.5 only
     plan->geometry = geometry;
@@ -598,6 +600,24 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 P->v_quad2.probs.push_back(g);
             }
         }
+    if (P->geometry == PSGDK_GEOM_QEP)
+        for (size_t f = 0; f < P->dn.size(); ++f) {
+            // term1 = Gram_i(Q_i Pg) = Q T1 Q^T with T1 the mode Gram of Pg; term2 = c Q Q^T (psgd.py:353-361)
+            const DenseDesc& F = P->dn[f];
+            float* sc = (float*)(W + F.sc_off);
+            GemmProblem g{};
+            g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = g.ldq = F.dp; g.alpha = 1.f;
+            GemmProblem u = g; u.A = S + F.q_off; u.B = W + F.t1_off; u.C = W + F.r_off;               // U = Q T1 (T1 symmetric)
+            P->v_qep_u.probs.push_back(u);
+            GemmProblem t1 = g; t1.A = W + F.r_off; t1.B = S + F.q_off; t1.C = t1.Ct = W + F.t1_off; t1.flags = GF_SYM;   // U Q^T
+            P->v_qep_t1.probs.push_back(t1);
+            GemmProblem t2 = g; t2.A = t2.B = S + F.q_off; t2.C = t2.Ct = W + F.rq_off; t2.flags = GF_SYM; t2.alpha = F.c;
+            P->v_qep_t2.probs.push_back(t2);
+            GemmProblem q = g;                                                                          // Q' = Q - mu (term1 - term2) Q
+            q.A = W + F.r_off; q.B = S + F.qt_off; q.C = W + F.qn_off; q.Ct = W + F.qtn_off;
+            q.flags = GF_QUPD; q.Qold = S + F.q_off; q.mu_dev = sc + DS_MU; q.c = 0.f;
+            P->e_qupd.probs.push_back(q);
+        }
     if (P->geometry == PSGDK_GEOM_EQ) {
         // ---- triangular geometry (psgd.py:278-336) ----
         P->e_gram_prob.assign(P->dn.size(), -1);
@@ -722,7 +742,8 @@ int psgdk_state_changed(psgdk_plan* plan, void* stream) {
 // balancing (psgd.py:266-275, drawn at psgd.py:318 / 418)
 static int run_balance(psgdk_plan* P, const uint8_t* balance_mask, hipStream_t st) {
     if (balance_mask) {
-        std::vector<int> which;
+        std::vector<int>& which = P->h_balance;      // plan-owned staging for the async upload
+        which.clear();
         for (int t = 0; t < P->n_tensors; ++t)
             if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN) which.push_back(t);
         for (size_t gi = 0; gi < P->gd.size(); ++gi)
@@ -809,6 +830,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5;
     if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || (need_skh && !noise->skh_noise))))) return PSGDK_ERR_INVALID;
     const float lr_eff = variant == PSGDK_GEOM_QUAD ? 0.5f * lr : lr;       // QUAD takes two half steps (psgd.py:473,479-480)
+    const bool qep = variant == PSGDK_GEOM_QEP;
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
@@ -832,6 +854,11 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
     HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
+        std::vector<uint8_t> all(P->n_tensors, 1);
+        if ((rc = run_balance(P, all.data(), st))) return rc;
+        P->p_valid = false;
+    }
     // damped input X (psgd.py:402-403), unless psgdk_accumulate already produced exactly this X
     const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
                          P->x_offset == offset && P->x_explicit == (noise != nullptr);
@@ -881,10 +908,25 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr_eff, betaL, 1));
-        if (variant == PSGDK_GEOM_Q0P5EQ1P5) {
+        if (!qep) {
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
+            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
+        }
+        if (qep) {
+            // term1 = Q T1 Q^T (-> t1), term2 = c Q Q^T (-> rq); S = term1 + term2 (-> t1), D = term1 - term2 (-> r)
+            launch_stage(P, P->v_qep_u, st);
+            launch_stage(P, P->v_qep_t1, st);
+            launch_stage(P, P->v_qep_t2, st);
+            DISPATCH_T(P, hipLaunchKernelGGL(zero_scalar_kernel, dim3((F + 63) / 64), dim3(64), 0, st, P->d_dn, P->work, (int)F, (int)DS_NF));
+            DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0));
+            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
+            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
+        }
+        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr_eff, betaL, qep ? 0 : 1));
+        if (qep) {
+            launch_stage(P, P->e_qupd, st);       // Q' = Q - mu (term1 - term2) Q (psgd.py:364)
+            DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
+        } else if (variant == PSGDK_GEOM_Q0P5EQ1P5) {
             // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
             launch_stage(P, P->g_qupd, st);
             // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
@@ -906,7 +948,14 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
         }
     }
     // diagonal factors (psgd.py:406-410); after every GEMM that still reads the old diagonals
-    if (!P->dd.empty())
+    if (!P->dd.empty() && qep) {
+        float* mu = (float*)(P->work + P->diag_mu_off);
+        const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
+        DISPATCH_T(P, hipLaunchKernelGGL(qep_diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
+                                         P->work, mu, 0, lr, betaL));
+        DISPATCH_T(P, hipLaunchKernelGGL(qep_diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
+                                         P->state, P->work, mu, 1, lr, betaL));
+    } else if (!P->dd.empty())
     {
         float* mu = (float*)(P->work + P->diag_mu_off);
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
@@ -915,7 +964,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
                                          P->state, P->work, mu, 1, lr_eff, betaL, variant == PSGDK_GEOM_QUAD ? 1 : 0));
     }
-    if ((rc = run_balance(P, balance_mask, st))) return rc;
+    if (!qep && (rc = run_balance(P, balance_mask, st))) return rc;
     HIPCHK(hipGetLastError());
     P->p_valid = false;
     return PSGDK_OK;
@@ -932,6 +981,10 @@ int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL
 int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                               uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
     return update_whiten_family(plan, PSGDK_GEOM_QUAD, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                             uint64_t seed, uint64_t offset, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_QEP, source, lr, betaL, damping, noise, seed, offset, nullptr, stream);
 }
 
 int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL, float damping,
@@ -989,7 +1042,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
             }
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
-        DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1));
         // ell = ||term1 + term2||_lb, L, mu (psgd.py:314-315 -> 46-68)
         DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
         for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);

@@ -21,11 +21,11 @@ class KronEngine:
                  tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5"):
         """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124).
         tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices).
-        geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5", "EQ" (upper-triangular Q), "QEQ", "QUAD"."""
+        geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5", "EQ" (upper-triangular Q), "QEQ", "QUAD", "QEP"."""
         codes = {"Q0.5EQ1.5": L.GEOM_Q0P5EQ1P5, "Q0p5EQ1p5": L.GEOM_Q0P5EQ1P5, "EQ": L.GEOM_EQ, "QEQ": L.GEOM_QEQ,
-                 "QUAD": L.GEOM_QUAD}
+                 "QUAD": L.GEOM_QUAD, "QEP": L.GEOM_QEP}
         if geometry not in codes:
-            raise NotImplementedError(f"dQ={geometry!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD")
+            raise NotImplementedError(f"dQ={geometry!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD, QEP")
         self.geometry = codes[geometry]
         self.lib = L.lib()
         self.device = torch.device(device)
@@ -176,6 +176,11 @@ class KronEngine:
         bm = None
         if balance_mask is not None:
             bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
+        if self.geometry == L.GEOM_QEP:      # balances every tensor itself, first (psgd.py:346-347): no gate argument
+            L.check(self.lib.psgdk_update_precond_qep(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr,
+                                                      int(seed), int(offset), self._stream()), "update_precond")
+            self._keep_noise = keep
+            return
         fn = {L.GEOM_Q0P5EQ1P5: self.lib.psgdk_update_precond_q0p5eq1p5, L.GEOM_EQ: self.lib.psgdk_update_precond_eq,
               L.GEOM_QEQ: self.lib.psgdk_update_precond_qeq, L.GEOM_QUAD: self.lib.psgdk_update_precond_quad}[self.geometry]
         L.check(fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed), int(offset), bm,

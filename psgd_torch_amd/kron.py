@@ -3,7 +3,7 @@
     init_kron(t, Scale, max_size, max_skew, dQ)                         psgd.py:161
     update_precond_kron_whiten_q0p5eq1p5(QL, exprs, G, lr, betaL, damping)   psgd.py:394
     update_precond_kron_whiten_eq(QL, exprs, G, lr, betaL, damping)     psgd.py:330   (init_kron(..., dQ="EQ"))
-    update_precond_kron_whiten_qeq / _quad(QL, exprs, G, lr, betaL, damping)   psgd.py:367 / 455   (dQ="QEQ" / "QUAD")
+    update_precond_kron_whiten_qeq / _quad / _qep(QL, exprs, G, lr, betaL, damping)   psgd.py:367 / 455 / 339
     precond_grad_kron(QL, exprs, G)                                     psgd.py:322
 
 so that the three lines wrapped_as_torch_optimizer_for_ddp.py:84-86 can point here.  `exprs` -- compiled einsum
@@ -18,13 +18,13 @@ import torch
 from . import _lib as L
 from .engine import KronEngine
 
-_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD"}
+_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP"}
 
 
 def init_kron(t: torch.Tensor, Scale=1.0, max_size=float("inf"), max_skew=1.0, dQ="Q0.5EQ1.5"):
     """psgd.py:161-263.  Returns [[Q, L], exprs]; t must live on a ROCm device in bf16 or fp32."""
     if dQ not in _SUPPORTED_DQ:
-        raise NotImplementedError(f"dQ={dQ!r}: built geometries are Q0.5EQ1.5 (the one KWNS4 uses), EQ, QEQ and QUAD")
+        raise NotImplementedError(f"dQ={dQ!r}: built geometries are Q0.5EQ1.5 (the one KWNS4 uses), EQ, QEQ, QUAD and QEP")
     if t.dim() > 26:
         raise ValueError(f"Got tensor with dim {t.dim()}; einsum runs out of letters; replace 26 with larger numbers.")
     if torch.is_complex(t):
@@ -90,6 +90,11 @@ def update_precond_kron_whiten_qeq(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9
 def update_precond_kron_whiten_quad(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9, *, noise=None, balance=None):
     """psgd.py:455-483 (quadratic form, symmetric Q; QL/exprs from init_kron(..., dQ="QUAD")), in place on QL."""
     _update_family(L.GEOM_QUAD, "QUAD", QL, exprs, G, lr, betaL, damping, noise, balance)
+
+
+def update_precond_kron_whiten_qep(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9, *, noise=None):
+    """psgd.py:339-364 (dQ = Q*E*P; balances on every call; QL/exprs from init_kron(..., dQ="QEP")), in place on QL."""
+    _update_family(L.GEOM_QEP, "QEP", QL, exprs, G, lr, betaL, damping, noise, False)
 
 
 def precond_grad_kron(QL, exprs, G):

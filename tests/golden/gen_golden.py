@@ -312,7 +312,8 @@ def gen_kron_eq_case(name, shape, dtypes, T, max_skew=1.0, max_size=float("inf")
 def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=float("inf"), Scale=1.0, lr=0.3, betaL=0.9,
                        damping=1e-9, force_balance_at=None, seed=0):
     """The QEQ / QUAD geometries (psgd.py:367-391, 455-483) behind the same seam."""
-    fn = {"QEQ": psgd.update_precond_kron_whiten_qeq, "QUAD": psgd.update_precond_kron_whiten_quad}[geom]
+    fn = {"QEQ": psgd.update_precond_kron_whiten_qeq, "QUAD": psgd.update_precond_kron_whiten_quad,
+          "QEP": psgd.update_precond_kron_whiten_qep}[geom]
     out = {"shape": np.asarray(shape, dtype=np.int64), "T": np.asarray(T), "max_skew": np.asarray(max_skew),
            "max_size": np.asarray(max_size), "Scale": np.asarray(Scale), "lr": np.asarray(lr),
            "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
@@ -329,14 +330,14 @@ def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=floa
             force = [0.001 if force_balance_at == t else 0.5]
             with Recorder(force_rand=force) as r:
                 fn(QL, exprs, G, lr=lr, betaL=betaL, damping=damping)
-            assert len(r.draws) == 1 + ndense + 1, (len(r.draws), ndense)
+            assert len(r.draws) == 1 + ndense + (0 if geom == "QEP" else 1), (len(r.draws), ndense)
             out[f"{dn}_t{t}_gnoise"] = npy(r.draws[0][1])
             k = 1
             for i, q in enumerate(QL[0]):
                 if q.dim() == 2:
                     out[f"{dn}_t{t}_spd{i}"] = npy(r.draws[k][1])
                     k += 1
-            out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1])
+            out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1]) if geom != "QEP" else np.asarray(0.5)   # QEP draws no gate
             out[f"{dn}_t{t}_h"] = npy(psgd.precond_grad_kron(QL, exprs, G))
             for i, (q, ell) in enumerate(zip(*QL)):
                 out[f"{dn}_t{t}_Q{i}"] = npy(q)
@@ -346,7 +347,7 @@ def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=floa
 
 def gen_kron_geoms():
     all3 = ("fp64", "fp32", "bf16")
-    for k, geom in enumerate(("QEQ", "QUAD")):
+    for k, geom in enumerate(("QEQ", "QUAD", "QEP")):
         b = 70 + 10 * k
         gen_kron_geom_case(geom, "vec33", (33,), all3, T=4, seed=b + 1)
         gen_kron_geom_case(geom, "m48x32", (48, 32), all3, T=8, seed=b + 2)

@@ -147,15 +147,21 @@ def test_kronwhiten_eq_optimises():
                 assert float(torch.tril(q, -1).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_"))
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_"))
 def test_qeq_quad_functional_seam_vs_golden(name):
     """dQ = "QEQ" (psgd.py:367-391) and "QUAD" (psgd.py:455-483) through the C ABI vs the reference's outputs; Q itself is
     compared (neither geometry has the Procrustes gauge step)."""
     import psgd_torch_amd as amd
-    qeq = name.startswith("kronqeq_")
-    geom = "QEQ" if qeq else "QUAD"
-    upd_amd = amd.update_precond_kron_whiten_qeq if qeq else amd.update_precond_kron_whiten_quad
-    upd_orc = orc.update_precond_kron_whiten_qeq if qeq else orc.update_precond_kron_whiten_quad
+    geom = {"kronqeq": "QEQ", "kronquad": "QUAD", "kronqep": "QEP"}[name.split("_")[0]]
+    qeq = geom != "QUAD"
+    upd_orc = {"QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
+               "QEP": orc.update_precond_kron_whiten_qep}[geom]
+
+    def upd_amd(QL, exprs, G, balance=None, **kw):
+        if geom == "QEP":
+            return amd.update_precond_kron_whiten_qep(QL, exprs, G, **kw)
+        fn = amd.update_precond_kron_whiten_qeq if geom == "QEQ" else amd.update_precond_kron_whiten_quad
+        return fn(QL, exprs, G, balance=balance, **kw)
     z = load(name)
     lr, betaL, damping = float(z["lr"]), float(z["betaL"]), float(z["damping"])
     kw = dict(Scale=float(z["Scale"]), max_size=float(z["max_size"]), max_skew=float(z["max_skew"]))

@@ -84,10 +84,11 @@ def test_kron_eq_update_and_apply(name):
                     assert float(torch.tril(q, -1).abs().max()) == 0.0        # Q stays upper triangular
 
 
-@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_"))
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_"))
 def test_kron_qeq_quad_update_and_apply(name):
-    """The QEQ / QUAD geometries (psgd.py:367-391, 455-483) against the reference's own outputs."""
-    fn = orc.update_precond_kron_whiten_qeq if name.startswith("kronqeq_") else orc.update_precond_kron_whiten_quad
+    """The QEQ / QUAD / QEP geometries (psgd.py:367-391, 455-483, 339-364) against the reference's own outputs."""
+    fn = {"kronqeq": orc.update_precond_kron_whiten_qeq, "kronquad": orc.update_precond_kron_whiten_quad,
+          "kronqep": orc.update_precond_kron_whiten_qep}[name.split("_")[0]]
     z = load(name)
     for dn in kron_dtypes(z):
         dt = DT[dn]
