@@ -113,6 +113,17 @@ class KWNS4(torch.optim.Optimizer):
         self._global_step = 0
         self._replay = None
 
+    # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
+    # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
+    def _data_of(self, p: torch.Tensor) -> torch.Tensor:
+        return p
+
+    def _grad_of(self, p: torch.Tensor) -> torch.Tensor:
+        return p.grad
+
+    def _has_work(self, p: torch.Tensor) -> bool:
+        return p.grad is not None                                                    # ..._ddp.py:113-115
+
     # hook for tests that replay the reference's recorded draws
     def _uniform(self) -> float:
         return float(torch.rand([], generator=self._gate_gen))
@@ -128,7 +139,8 @@ class KWNS4(torch.optim.Optimizer):
 
     # --------------------------------------------------------------------------------------------------------------
     def _bucket_for(self, gi: int, group, plist: List[torch.Tensor]) -> _Bucket:
-        key = (gi, plist[0].dtype, plist[0].grad.dtype, plist[0].device)
+        p0, g0 = self._data_of(plist[0]), self._grad_of(plist[0])
+        key = (gi, p0.dtype, g0.dtype, p0.device)
         b = self._buckets.get(key)
         if b is not None:
             if [id(p) for p in b.params] != [id(p) for p in plist]:
@@ -137,8 +149,11 @@ class KWNS4(torch.optim.Optimizer):
             return b
         b = _Bucket()
         b.params = list(plist)
-        pd = group["preconditioner_dtype"] or plist[0].grad.dtype
-        shapes = [tuple(p.grad.squeeze().shape) for p in plist]                      # ..._ddp.py:124
+        # Philox stream ids = position of the parameter in its group: the same on every rank, whatever subset of the group
+        # a rank works on (sharded ownership; DTensor ranks whose local shard of some parameter is empty)
+        pos = {id(p): k for k, p in enumerate(group["params"])}
+        pd = group["preconditioner_dtype"] or g0.dtype
+        shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]            # ..._ddp.py:124
         if self.shard_state:
             costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
             owner = lpt_partition(costs, self.world)
@@ -149,12 +164,12 @@ class KWNS4(torch.optim.Optimizer):
             b.owned = list(range(len(plist)))
         b.shapes = shapes
         if b.owned:
-            b.engine = self._engine_factory([shapes[i] for i in b.owned], plist[0].device, precond_dtype=pd,
+            b.engine = self._engine_factory([shapes[i] for i in b.owned], p0.device, precond_dtype=pd,
                                             max_size=group["preconditioner_max_size"],
                                             max_skew=group["preconditioner_max_skew"],
                                             use_momentum=group["momentum"] > 0.0,
                                             init_scale=group["preconditioner_init_scale"],   # ..._ddp.py:131-137
-                                            tensor_ids=[(len(self._buckets) << 20) + i for i in b.owned])
+                                            tensor_ids=[(gi << 20) + pos[id(plist[i])] for i in b.owned])
             for k, i in enumerate(b.owned):
                 st = self.state[plist[i]]
                 st["QL"] = b.engine.QL(k)
@@ -168,7 +183,7 @@ class KWNS4(torch.optim.Optimizer):
             per_rank = [sum(numels[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
             seg = max(per_rank + [1])
             b.seg = seg
-            b.flat = torch.zeros(self.world * seg, dtype=pd, device=plist[0].device)
+            b.flat = torch.zeros(self.world * seg, dtype=pd, device=p0.device)
             offs = [r * seg for r in range(self.world)]
             b.h_views = []
             for i, s in enumerate(shapes):
@@ -190,12 +205,13 @@ class KWNS4(torch.optim.Optimizer):
                 updateP_first, updateP_last = group["update_preconditioner_first"], not group["update_preconditioner_first"]
             else:
                 updateP_first, updateP_last = False, False
-            with_grad = [p for p in group["params"] if p.grad is not None]            # ..._ddp.py:113-115
+            with_grad = [p for p in group["params"] if self._has_work(p)]             # ..._ddp.py:113-115
             if not with_grad:
                 continue
             by_dtype: Dict[tuple, List[torch.Tensor]] = {}
             for p in with_grad:
-                by_dtype.setdefault((p.dtype, p.grad.dtype, p.device), []).append(p)
+                lp, lg = self._data_of(p), self._grad_of(p)
+                by_dtype.setdefault((lp.dtype, lg.dtype, lp.device), []).append(p)
             for plist in by_dtype.values():
                 self._step_bucket(gi, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
         self._global_step += 1
@@ -210,8 +226,9 @@ class KWNS4(torch.optim.Optimizer):
         src_p = L.SRC_GRAD if momentum == 0.0 else L.SRC_EMA                          # ..._ddp.py:150
         eng = b.engine
         if eng is not None:
-            own_p = [plist[i] for i in b.owned]
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in own_p]
+            own_p = [self._data_of(plist[i]) for i in b.owned]
+            grads = [self._grad_of(plist[i]) for i in b.owned]
+            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
             coupled = wd if (wd > 0.0 and not decoupled) else 0.0
             damp = None
             if (updateP_first or updateP_last) and self._replay is None:
@@ -238,19 +255,23 @@ class KWNS4(torch.optim.Optimizer):
             # ONE exchange step: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner is)
             mine = b.flat[self.rank * b.seg:(self.rank + 1) * b.seg]
             torch.distributed.all_gather_into_tensor(b.flat, mine.clone())
+            lps = [self._data_of(p) for p in plist]
             if wd > 0.0 and decoupled:
-                torch._foreach_mul_(plist, 1.0 - wd * lr)                             # ..._ddp.py:120
-            hs = [h.to(p.dtype).view_as(p) for h, p in zip(b.h_views, plist)]
-            torch._foreach_add_(plist, hs, alpha=-lr)                                 # ..._ddp.py:157
+                torch._foreach_mul_(lps, 1.0 - wd * lr)                               # ..._ddp.py:120
+            hs = [h.to(p.dtype).view_as(p) for h, p in zip(b.h_views, lps)]
+            torch._foreach_add_(lps, hs, alpha=-lr)                                   # ..._ddp.py:157
         b.step += 1
         for p in plist:
             self.state[p]["step"] += 1
         # ..._ddp.py:163-170: periodic resync of replicated state from rank 0 (drift from non-deterministic atomics)
         if self.is_distributed and not self.shard_state and (b.step % group["resync_every"] == 0):
-            for p in plist:
-                torch.distributed.broadcast(p, src=0)
-            if eng is not None:
-                torch.distributed.broadcast(eng.state_arena, src=0)
+            self._resync(b, plist)
+
+    def _resync(self, b, plist):
+        for p in plist:
+            torch.distributed.broadcast(p, src=0)
+        if b.engine is not None:
+            torch.distributed.broadcast(b.engine.state_arena, src=0)
 
     # ------------------------------------------------------------------------------------------------------------------
     # checkpoint / resume.  The reference offers none that works: its state holds opt_einsum expression objects and its
