@@ -194,3 +194,25 @@ def test_qeq_quad_functional_seam_vs_golden(name):
                     floor = 4e-2 if what.startswith("L") else 2e-2
                     e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
+
+
+@pytest.mark.parametrize("dQ", ["QEQ", "QUAD", "QEP"])
+def test_kronwhiten_other_geometries_optimise(dQ):
+    """KronWhiten(dQ=...) on an ill-conditioned least-squares problem: converges by orders of magnitude."""
+    from psgd_torch_amd import KronWhiten
+    torch.manual_seed(0)
+    shapes = [(24, 40), (40,), (16, 16), (3, 4, 5)]
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    targets = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    scales = [(0.1 + 3 * torch.rand(s, generator=g)).to(DEV) for s in shapes]
+    opt = KronWhiten(ps, preconditioner_init_scale=1.0, whiten_grad=False, lr_params=0.05, lr_preconditioner=0.2,
+                     momentum=0.9, preconditioner_max_skew=2.0, dQ=dQ)
+
+    def loss():
+        return sum((((p - t) * s) ** 2).sum() for p, t, s in zip(ps, targets, scales))
+    l0 = float(loss().detach())
+    for _ in range(300):
+        opt.step(loss)
+    l1 = float(loss().detach())
+    assert l1 < 1e-3 * l0, (dQ, l0, l1)

@@ -301,3 +301,35 @@ def test_kwns4_checkpoint_resume():
     run(ob, pb, range(3, 6))
     for a, b in zip(pa, pb):
         assert relerr(a.data, b.data) < 1e-6, relerr(a.data, b.data)
+
+
+@pytest.mark.parametrize("dn", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape,max_skew", [((48, 64), float("inf")), ((40, 24), 1.0), ((33,), 1.0)])
+def test_degenerate_gradients(shape, max_skew, dn):
+    """Edge inputs the reference handles through its smallest_normal guards (psgd.py:59,66,84,118): an all-zero gradient
+    (term1 = 0, R = 0), then a tiny and a huge one.  Nothing may become NaN/Inf, and P, L, h must follow the oracle."""
+    amd = _amd()
+    dt = DT[dn]
+    QL, exprs = amd.init_kron(torch.zeros(shape, device=DEV, dtype=dt), Scale=1.0, max_skew=max_skew)
+    QLo, kinds = orc.init_kron(torch.zeros(shape, dtype=dt), Scale=1.0, max_skew=max_skew)
+    gen = torch.Generator().manual_seed(17)
+    for t, amp in enumerate([0.0, 1e-18, 1.0, 1e6, 0.0]):
+        G = (amp * torch.randn(shape, generator=gen)).to(dt)
+        noise = orc.KronNoise.draw(G, kinds, gen)
+        nz = (
+            [noise.g_noise.to(DEV)],
+            {(0, i): x.to(DEV) for i, x in enumerate(noise.spd) if x is not None},
+            {(0, i): x.to(DEV) for i, x in enumerate(noise.skh) if x is not None},
+        )
+        amd.update_precond_kron_whiten_q0p5eq1p5(QL, exprs, G.to(DEV), lr=0.3, betaL=0.9, damping=1e-9, noise=nz, balance=False)
+        noise.balance_u = 1.0
+        orc.update_precond_kron_whiten_q0p5eq1p5(QLo, G, noise, lr=0.3, betaL=0.9, damping=1e-9)
+        h = amd.precond_grad_kron(QL, exprs, G.to(DEV))
+        ho = orc.precond_grad_kron(QLo[0], G)
+        tol = 2e-4 if dn == "fp32" else 6e-2
+        assert torch.isfinite(h).all()
+        assert relerr(h, ho) <= tol or float(ho.abs().max()) == 0.0, (shape, dn, t, relerr(h, ho))
+        for i in range(len(QL[0])):
+            assert torch.isfinite(QL[0][i]).all() and torch.isfinite(QL[1][i]).all()
+            assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= tol, (shape, dn, t, i, "P")
+            assert relerr(QL[1][i], QLo[1][i]) <= tol, (shape, dn, t, i, "L")
