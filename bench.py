@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test "
+                                                      "the multi-rank code path with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
     if args.config == "vit-b-lra":
         return bench_lra(args)
@@ -167,12 +170,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP engine)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = world > 1
     if dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend=args.backend)
 
     import psgd_torch_amd
     if args.config == "gpt2-medium":
