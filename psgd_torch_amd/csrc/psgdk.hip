@@ -1309,7 +1309,7 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
         hipLaunchKernelGGL(lra_prep_kernel<T>, dim3(gb), dim3(256), 0, st, (const T*)g, (const T*)v_noise, v, h, N, damping, seed, offset);
         if (r > 0) {
             hipLaunchKernelGGL(lra_gram_kernel<T>, dim3(std::min<unsigned>(gb, 1024)), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm);
-            hipLaunchKernelGGL(lra_small1_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
+            hipLaunchKernelGGL(lra_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, r);
         }
         hipLaunchKernelGGL(lra_rotate_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
         hipLaunchKernelGGL(lra_small2_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
