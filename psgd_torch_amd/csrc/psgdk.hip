@@ -1291,6 +1291,16 @@ int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void*
 
 #define LRA_T(L, CALL) do { if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; CALL; } else { typedef float T; CALL; } } while (0)
 
+// launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of 256 x r floats, and as many workgroups as are
+// resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
+static void lra_geometry(int64_t N, int r, int mats, unsigned* grid, unsigned* shm) {
+    const unsigned bytes = (unsigned)std::max(16, mats * LRA_ROWS * r * 4);
+    const unsigned per_cu = std::max(1u, std::min(8u, (160u * 1024u) / (bytes + 1024u)));
+    const int64_t blocks = (N + LRA_ROWS - 1) / LRA_ROWS;
+    *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * (int64_t)per_cu));
+    *shm = bytes;
+}
+
 int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
                             float lr, float betaL, float damping, void* stream) {
     if (!lra || !g) return PSGDK_ERR_INVALID;
@@ -1301,6 +1311,8 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
     float* sm = (float*)(L->work + L->sm_off);
     const int64_t N = L->N; const int r = L->r;
     const unsigned gb = (unsigned)std::min<int64_t>((N + LRA_ROWS - 1) / LRA_ROWS, 2048);
+    unsigned gb1, gb2, shm1, shm2;
+    lra_geometry(N, r, 1, &gb1, &shm1); lra_geometry(N, r, 2, &gb2, &shm2);
     HIPCHK(hipMemsetAsync(sm, 0, (size_t)LS_TOTAL * 4, st));
     LRA_T(L, {
         T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
@@ -1308,18 +1320,18 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
         hipLaunchKernelGGL(lra_prep_kernel<T>, dim3(gb), dim3(256), 0, st, (const T*)g, (const T*)v_noise, v, h, N, damping, seed, offset);
         if (r > 0) {
-            hipLaunchKernelGGL(lra_gram_kernel<T>, dim3(std::min<unsigned>(gb, 1024)), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm);
+            hipLaunchKernelGGL(lra_gram_kernel<T>, dim3(gb2), dim3(256), shm2, st, (const T*)U, (const T*)V, N, r, sm);
             hipLaunchKernelGGL(lra_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, r);
         }
-        hipLaunchKernelGGL(lra_rotate_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+        hipLaunchKernelGGL(lra_rotate_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
         hipLaunchKernelGGL(lra_small2_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL(lra_pass3_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+        hipLaunchKernelGGL(lra_pass3_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
                            (const T*)h, Qh, iq, N, r, sm);
         hipLaunchKernelGGL(lra_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL(lra_pass4_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+        hipLaunchKernelGGL(lra_pass4_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
                            (const T*)h, (const T*)Qh, (const T*)iq, diff, N, r, sm);
         hipLaunchKernelGGL(lra_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
-        hipLaunchKernelGGL(lra_pass5_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+        hipLaunchKernelGGL(lra_pass5_kernel<T>, dim3(gb1), dim3(LRA_ROWS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                            N, r, update_u ? 1 : 0, (const float*)sm);
     });
     HIPCHK(hipGetLastError());
@@ -1332,12 +1344,13 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
     psgdk_lra* L = lra;
     hipStream_t st = (hipStream_t)stream;
     float* sm = (float*)(L->work + L->sm_off);
-    const unsigned gb = (unsigned)std::min<int64_t>((L->N + LRA_ROWS - 1) / LRA_ROWS, 2048);
+    unsigned gb1, shm1;
+    lra_geometry(L->N, L->r, 1, &gb1, &shm1);
     HIPCHK(hipMemsetAsync(sm + LS_VTX2, 0, 32 * 4, st));
     LRA_T(L, {
         T* y = (T*)(L->work + L->y_off);
         for (int stage = 0; stage < 3; ++stage)
-            hipLaunchKernelGGL(lra_apply_kernel<T>, dim3(gb), dim3(LRA_ROWS), 0, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+            hipLaunchKernelGGL(lra_apply_kernel<T>, dim3(gb1), dim3(LRA_ROWS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                                (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
     });
     HIPCHK(hipGetLastError());
