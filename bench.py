@@ -236,6 +236,21 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # secondary figure: the apply-only step, i.e. the steady state once the update probability is annealed down
+    # (momentum + precondition + clip + parameter update; the preconditioner update gated off).  Outside the timed region.
+    apply_only_ms = None
+    if not dist:
+        for g in opt.param_groups:
+            g["preconditioner_update_probability"] = 1e-12
+        for i in range(3):
+            one_step(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(10):
+            one_step(i)
+        fence()
+        apply_only_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     ms_per_step = dt / args.steps * 1e3
     step_flops, gemm_flops = flop_model(shapes)
     run_cpu = args.config == "gpt2-small"
@@ -259,7 +274,8 @@ def main():
                                + "; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
                    "parallelism": "single GPU" if world == 1 else f"per-parameter state sharding x{world} + all-gather",
-                   "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3},
+                   "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                   "apply_only_ms_per_step": apply_only_ms},
     }
     if world == 1 and gemm_launches:
         launches_per_step = gemm_launches / args.steps
