@@ -509,6 +509,8 @@ def gen_lra():
     gen_lra_case("n10_r5", 10, 5, ("fp64", "fp32"), T=6, seed=1)
     gen_lra_case("n2048_r10", 2048, 10, ("fp64", "fp32", "bf16"), T=3, seed=2)
     gen_lra_case("n257_r1", 257, 1, ("fp64", "fp32"), T=4, lr=0.3, betaL=0.5, damping=1e-3, seed=3)
+    gen_lra_case("n300_r0", 300, 0, ("fp64", "fp32", "bf16"), T=3, seed=4)          # rank 0 = diagonal preconditioner
+    gen_lra_case("n4096_r16", 4096, 16, ("fp32", "bf16"), T=3, seed=5)               # the largest rank the HIP kernels hold
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)
