@@ -112,6 +112,8 @@ class KWNS4(torch.optim.Optimizer):
         self._engine_factory = engine_factory or KronEngine
         self._global_step = 0
         self._replay = None
+        self._split = set()          # bucket keys that fell back to one engine per parameter
+        self._split_pd = {}
 
     # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
     # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
@@ -138,22 +140,68 @@ class KWNS4(torch.optim.Optimizer):
         return dict(noise=None, balance_mask=[u[i] < 0.01 for i in b.owned])
 
     # --------------------------------------------------------------------------------------------------------------
-    def _bucket_for(self, gi: int, group, plist: List[torch.Tensor]) -> _Bucket:
+    def _buckets_for(self, gi: int, group, plist: List[torch.Tensor]):
+        """[(bucket, params)] covering plist.  Normally one batched bucket.  If the set of parameters with gradients changes
+        between steps (the reference simply skips parameters without a gradient, ..._ddp.py:113-115) the batched bucket is
+        SPLIT once into one single-tensor engine per parameter -- state carried over -- and stays split: correct for any
+        pattern of missing gradients, at the reference's own launch granularity for that group."""
         p0, g0 = self._data_of(plist[0]), self._grad_of(plist[0])
         key = (gi, p0.dtype, g0.dtype, p0.device)
+        pos = {id(p): k for k, p in enumerate(group["params"])}
+        if key in self._split:
+            out = []
+            for p in plist:
+                sk = key + ("p", pos[id(p)])
+                if sk not in self._buckets:
+                    self._bucket_for(gi, group, [p], key=sk, pd=self._split_pd.get(key))
+                out.append((self._buckets[sk], [p]))
+            return out
+        b = self._buckets.get(key)
+        if b is not None and [id(p) for p in b.params] != [id(p) for p in plist]:
+            if self.shard_state:
+                raise RuntimeError("KWNS4 (HIP engine, shard_state=True): the set of parameters with gradients changed "
+                                   "between steps; per-step parameter skipping is only built for the replicated mode")
+            self._split_bucket(gi, group, key, b, pos)
+            return self._buckets_for(gi, group, plist)
+        return [(self._bucket_for(gi, group, plist), plist)]
+
+    def _split_bucket(self, gi, group, key, b, pos):
+        self._split.add(key)
+        self._split_pd[key] = b.pd
+        del self._buckets[key]
+        for k, p in enumerate(b.params):
+            sk = key + ("p", pos[id(p)])
+            nb = self._bucket_for(gi, group, [p], key=sk, shapes=[b.shapes[k]], pd=b.pd)
+            nb.step = b.step
+            self.state[p]["step"] = b.step
+            oldQ, oldL = b.engine.QL(k)
+            newQ, newL = nb.engine.QL(0)
+            for src, dst in zip(oldQ, newQ):
+                dst.copy_(src)
+            for src, dst in zip(oldL, newL):
+                dst.copy_(src)
+            if group["momentum"] > 0.0:
+                nb.engine.ema[0].copy_(b.engine.ema[k])
+            nb.engine.state_changed()
+        b.engine = None
+
+    def _bucket_for(self, gi: int, group, plist: List[torch.Tensor], key=None, shapes=None, pd=None) -> _Bucket:
+        p0 = self._data_of(plist[0])
+        if key is None:
+            key = (gi, p0.dtype, self._grad_of(plist[0]).dtype, p0.device)
         b = self._buckets.get(key)
         if b is not None:
-            if [id(p) for p in b.params] != [id(p) for p in plist]:
-                raise RuntimeError("KWNS4 (HIP engine): the set of parameters with gradients changed between steps; "
-                                   "per-step parameter skipping (..._ddp.py:114-115) is not built into the batched engine yet")
             return b
         b = _Bucket()
         b.params = list(plist)
         # Philox stream ids = position of the parameter in its group: the same on every rank, whatever subset of the group
         # a rank works on (sharded ownership; DTensor ranks whose local shard of some parameter is empty)
         pos = {id(p): k for k, p in enumerate(group["params"])}
-        pd = group["preconditioner_dtype"] or g0.dtype
-        shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]            # ..._ddp.py:124
+        if pd is None:
+            pd = group["preconditioner_dtype"] or self._grad_of(plist[0]).dtype
+        if shapes is None:
+            shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]        # ..._ddp.py:124
+        b.pd = pd
         if self.shard_state:
             costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
             owner = lpt_partition(costs, self.world)
@@ -213,11 +261,11 @@ class KWNS4(torch.optim.Optimizer):
                 lp, lg = self._data_of(p), self._grad_of(p)
                 by_dtype.setdefault((lp.dtype, lg.dtype, lp.device), []).append(p)
             for plist in by_dtype.values():
-                self._step_bucket(gi, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
+                for b, sub in self._buckets_for(gi, group, plist):
+                    self._step_bucket(b, group, sub, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
         self._global_step += 1
 
-    def _step_bucket(self, gi, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
-        b = self._bucket_for(gi, group, plist)
+    def _step_bucket(self, b, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
         wd, lr = group["weight_decay"], group["lr_params"]
         decoupled = group["decoupled_weight_decay"]
         t = b.step

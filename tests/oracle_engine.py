@@ -81,3 +81,6 @@ class OracleEngine:
             return h.clone()
         out.copy_(h.reshape(out.shape))
         return out
+
+    def state_changed(self):
+        pass

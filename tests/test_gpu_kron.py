@@ -333,3 +333,35 @@ def test_degenerate_gradients(shape, max_skew, dn):
             assert torch.isfinite(QL[0][i]).all() and torch.isfinite(QL[1][i]).all()
             assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= tol, (shape, dn, t, i, "P")
             assert relerr(QL[1][i], QLo[1][i]) <= tol, (shape, dn, t, i, "L")
+
+
+def test_kwns4_split_on_changing_gradient_set():
+    """A parameter that has a gradient only on the first step makes the batched bucket split into per-parameter engines
+    (state carried over).  The other parameters must follow the trajectory of a run in which that parameter never had a
+    gradient (same Philox stream ids = positions in the group, same per-parameter offsets), and the parameter itself must
+    stay untouched while it has no gradient."""
+    amd = _amd()
+    shapes = [(48, 32), (32,), (24, 24), (3, 4, 5), (20, 30)]
+
+    def run(extra_first_step):
+        g = torch.Generator().manual_seed(11)
+        ps = [torch.nn.Parameter((0.5 * torch.randn(s, generator=g)).to(DEV)) for s in shapes + [(16, 8)]]
+        opt = amd.KWNS4(ps, preconditioner_dtype=torch.float32, lr_params=1e-2, seed=3)
+        gg = torch.Generator().manual_seed(12)
+        snap = None
+        for t in range(5):
+            for i, p in enumerate(ps):
+                gi = (0.3 * torch.randn(p.shape, generator=gg)).to(DEV)
+                p.grad = gi if (i < len(shapes) or (extra_first_step and t == 0)) else None
+            opt.step()
+            if t == 0:
+                snap = ps[-1].detach().clone()
+        return ps, opt, snap
+    pa, oa, _ = run(False)
+    pb, ob, snap = run(True)
+    assert len(ob._split) == 1 and len(oa._split) == 0
+    assert torch.equal(pb[-1].data, snap), "a parameter without gradient must not move"
+    assert ob.state[pb[-1]]["step"] == 1
+    for a, b in zip(pa[:-1], pb[:-1]):
+        assert relerr(b.data, a.data) <= 1e-5, relerr(b.data, a.data)
+        assert ob.state[b]["step"] == 5
