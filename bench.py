@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank code path with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "sharded", "replicated"],
+                    help="N > 1: per-parameter state sharding + one all-gather per step, or replicas (the reference's DDP "
+                         "semantics, no exchange); auto times both during warm-up and keeps the faster one")
     args = ap.parse_args()
     if args.config == "vit-b-lra":
         return bench_lra(args)
@@ -194,16 +197,54 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234)
     params = [torch.nn.Parameter(0.02 * torch.randn(*s, device=dev, generator=gen)) for s in shapes]
     pd = torch.float32 if args.fp32 else torch.bfloat16
-    opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=pd, shard_state=dist)   # reference defaults otherwise
     # synthetic gradient streams resident in HBM: a few distinct draws, cycled
     n_sets = 2
     grad_sets = [[0.01 * torch.randn(*s, device=dev, generator=gen) for s in shapes] for _ in range(n_sets)]
 
-    def one_step(i):
-        gs = grad_sets[i % n_sets]
-        for p, g in zip(params, gs):
-            p.grad = g
-        opt.step()
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    def make(shard):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, shard_state=shard)   # reference defaults otherwise
+
+    def step_of(ps, o):
+        def f(i):
+            gs = grad_sets[i % n_sets]
+            for p, g in zip(ps, gs):
+                p.grad = g
+            o.step()
+        return f
+
+    # N > 1: the path shards per parameter (state + compute on the owner, ONE all-gather of the clipped preconditioned
+    # gradients per step) -- worthwhile when the exchange costs less than the compute it saves, which depends on N and the
+    # fabric.  Both modes give every rank the same parameters; auto keeps the faster one (timed here, untimed warm-up).
+    mode = "sharded" if dist else "single"
+    if dist and args.parallelism != "sharded":
+        mode = "replicated"
+    if dist and args.parallelism == "auto":
+        timing = {}
+        for name, shard in (("sharded", True), ("replicated", False)):
+            ps_, o_ = make(shard)
+            f_ = step_of(ps_, o_)
+            for i in range(3):
+                f_(i)
+            sync_all()
+            t_ = time.perf_counter()
+            for i in range(4):
+                f_(i)
+            sync_all()
+            tt = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            timing[name] = float(tt.item()) / 4
+            del ps_, o_, f_
+            torch.cuda.empty_cache()
+        mode = min(timing, key=timing.get)
+    params, opt = make(mode == "sharded")
+    one_step = step_of(params, opt)
 
     for i in range(args.warmup):
         one_step(i)
@@ -212,12 +253,7 @@ def main():
         e.profile_read(reset=True)
         e.profile_enable(True)
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
-
+    fence = sync_all
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -273,7 +309,9 @@ def main():
                                 "lenet5": f"LeNet5 parameter shapes (mnist_with_lenet5.py): 5 tensors, {nparam} params, fp32"}[args.config]
                                + "; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
-                   "parallelism": "single GPU" if world == 1 else f"per-parameter state sharding x{world} + all-gather",
+                   "parallelism": "single GPU" if world == 1 else (f"per-parameter state sharding x{world} + one all-gather per step"
+                                                                   if mode == "sharded" else f"replicas x{world} (no exchange step)"),
+                   "parallelism_probe_ms": ({k: v * 1e3 for k, v in timing.items()} if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                    "apply_only_ms_per_step": apply_only_ms},
     }
