@@ -352,8 +352,8 @@ def gen_kron_geoms():
         gen_kron_geom_case(geom, "vec33", (33,), all3, T=4, seed=b + 1)
         gen_kron_geom_case(geom, "m48x32", (48, 32), all3, T=8, seed=b + 2)
         gen_kron_geom_case(geom, "m32x48", (32, 48), all3, T=6, seed=b + 3)
-        gen_kron_geom_case(geom, "m64x64", (64, 64), all3, T=8, seed=b + 4, force_balance_at=3)
-        gen_kron_geom_case(geom, "m150x200", (150, 200), ("fp32", "bf16"), T=3, seed=b + 5)
+        gen_kron_geom_case(geom, "m64x64", (64, 64), all3, T=4, seed=b + 4, force_balance_at=2)
+        gen_kron_geom_case(geom, "m150x200", (150, 200), ("fp32", "bf16"), T=2, seed=b + 5)
         gen_kron_geom_case(geom, "t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=b + 6)
 
 
@@ -363,10 +363,10 @@ def gen_kron_eq():
     gen_kron_eq_case("vec33", (33,), all3, T=4, seed=52)
     gen_kron_eq_case("m48x32", (48, 32), all3, T=8, seed=53)                      # [diag, dense]
     gen_kron_eq_case("m32x48", (32, 48), all3, T=6, seed=54)                      # [dense, diag]
-    gen_kron_eq_case("m64x64", (64, 64), all3, T=8, seed=55, force_balance_at=3)  # [dense, dense] + balance branch
+    gen_kron_eq_case("m64x64", (64, 64), all3, T=4, seed=55, force_balance_at=2)  # [dense, dense] + balance branch
     gen_kron_eq_case("m24x40_diagdiag", (24, 40), all3, T=4, max_skew=0.0, seed=57)
-    gen_kron_eq_case("m150x200", (150, 200), ("fp32", "bf16"), T=4, seed=58)      # several 64-blocks per triangular solve
-    gen_kron_eq_case("m257x120", (257, 120), ("fp32", "bf16"), T=3, max_skew=float("inf"), seed=59)
+    gen_kron_eq_case("m150x200", (150, 200), ("fp32", "bf16"), T=2, seed=58)      # several 64-blocks per triangular solve
+    gen_kron_eq_case("m257x120", (257, 120), ("fp32", "bf16"), T=2, max_skew=float("inf"), seed=59)
     gen_kron_eq_case("t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=60)          # oracle only: N-D under EQ is not built
 
 
@@ -510,7 +510,7 @@ def gen_lra():
     gen_lra_case("n2048_r10", 2048, 10, ("fp64", "fp32", "bf16"), T=3, seed=2)
     gen_lra_case("n257_r1", 257, 1, ("fp64", "fp32"), T=4, lr=0.3, betaL=0.5, damping=1e-3, seed=3)
     gen_lra_case("n300_r0", 300, 0, ("fp64", "fp32", "bf16"), T=3, seed=4)          # rank 0 = diagonal preconditioner
-    gen_lra_case("n4096_r16", 4096, 16, ("fp32", "bf16"), T=3, seed=5)               # the largest rank the HIP kernels hold
+    gen_lra_case("n1000_r16", 1000, 16, ("fp32", "bf16"), T=3, seed=5)               # the largest rank the HIP kernels hold
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)
