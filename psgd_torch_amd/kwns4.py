@@ -33,6 +33,8 @@ class _Bucket:
         self.owned: List[int] = []          # indices into params this rank preconditions
         self.step = 0
         self.flat = None                     # sharded mode: gathered clipped h
+        self.flat_cast = None                # ... and its copy in the parameter dtype
+        self.h_cast_views = None
         self.segments = None
 
 
@@ -306,7 +308,15 @@ class KWNS4(torch.optim.Optimizer):
             lps = [self._data_of(p) for p in plist]
             if wd > 0.0 and decoupled:
                 torch._foreach_mul_(lps, 1.0 - wd * lr)                               # ..._ddp.py:120
-            hs = [h.to(p.dtype).view_as(p) for h, p in zip(b.h_views, lps)]
+            if b.flat.dtype != lps[0].dtype:
+                # one cast of the whole exchange buffer (not one per tensor), then a multi-tensor update
+                if b.flat_cast is None:
+                    b.flat_cast = torch.empty_like(b.flat, dtype=lps[0].dtype)
+                    b.h_cast_views = [b.flat_cast[v.storage_offset():v.storage_offset() + v.numel()].view(v.shape) for v in b.h_views]
+                b.flat_cast.copy_(b.flat)
+                hs = [h.view_as(p) for h, p in zip(b.h_cast_views, lps)]
+            else:
+                hs = [h.view_as(p) for h, p in zip(b.h_views, lps)]
             torch._foreach_add_(lps, hs, alpha=-lr)                                   # ..._ddp.py:157
         b.step += 1
         for p in plist:
