@@ -69,8 +69,7 @@ int psgdk_plan_destroy(psgdk_plan* plan);
 int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 /* Optional, before psgdk_plan_arena_bytes / psgdk_plan_bind: the update geometry the plan will be driven with -- the dQ
  * argument of psgd.init_kron (psgd.py:161).  PSGDK_GEOM_Q0P5EQ1P5 (default; dense Q, psgd.py:394-419) or PSGDK_GEOM_EQ
- * (upper-triangular Q, psgd.py:278-336; needs extra work buffers; tensors with more than 2 dims ->
- * PSGDK_ERR_UNSUPPORTED), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483), PSGDK_GEOM_QEP
+ * (upper-triangular Q, psgd.py:278-336; needs extra work buffers), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483), PSGDK_GEOM_QEP
  * (psgd.py:339-364).  The two geometries of the reference that fit P directly (QUAD4P, PRO4P) are not built.  Each update entry point below requires the plan to
  * carry its geometry (else PSGDK_ERR_STATE). */
 #define PSGDK_GEOM_Q0P5EQ1P5 0

@@ -150,8 +150,11 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
 // (kron_i F_i) applied mode by mode to an N-D tensor (psgd.py:251-252, exprP): F_i = P_i = Q_i^T Q_i (dense, from the
 // batched P stage) or diag(q_i^2).  src -> ping-pong buffers -> dst (dst may be one of the ping-pong buffers' owner h).
 // Returns the buffer holding the result when dst == nullptr.
+// what: 0 = P (Q^T Q / a^2, psgd.py:251-252 exprP), 1 = Q itself (a; exprA, psgd.py:248-249), 2 = the solves X inv(Q_i)
+// (X / a; psgd.py:297-303).  The ping-pong pair `pp` keeps the result alive while another chain runs through the other pair.
 template <typename T>
-static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T* dst, float* sumsq, hipStream_t st) {
+static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T* dst, float* sumsq, hipStream_t st, int what = 0,
+                                int pp = 0) {
     const int64_t numel = P->td[g.tensor].numel;
     const T* cur = src;
     int64_t A = 1;
@@ -159,13 +162,19 @@ static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T
         const int s_ = g.dims[i];
         const int64_t B = numel / (A * s_);
         const bool last = (i == g.ndim - 1);
-        T* out = (last && dst) ? dst : (T*)(P->work + g.pp_off[i & 1]);
+        T* out = (last && dst) ? dst : (T*)(P->work + (pp ? g.pp2_off[i & 1] : g.pp_off[i & 1]));
         const bool dense = g.fkind[i] == PSGDK_DENSE;
-        const T* F = dense ? (const T*)(P->work + P->dn[g.fidx[i]].p_off) : (const T*)(P->state + P->dd[g.fidx[i]].a_off);
+        const T* F = dense ? (what == 0 ? (const T*)(P->work + P->dn[g.fidx[i]].p_off) : (const T*)(P->state + P->dn[g.fidx[i]].q_off))
+                           : (const T*)(P->state + P->dd[g.fidx[i]].a_off);
         const int ldf = dense ? P->dn[g.fidx[i]].dp : 0;
-        const unsigned gb = (unsigned)std::min<int64_t>((numel + 255) / 256, 4096);
-        hipLaunchKernelGGL(gen_mode_apply_kernel<T>, dim3(gb), dim3(256), 0, st, cur, out, F, ldf, dense ? 1 : 0, (int)A, s_, (int)B,
-                           last ? sumsq : (float*)nullptr);
+        if (what == 2) {
+            const unsigned gb = (unsigned)std::min<int64_t>((A * B + 63) / 64, 4096);
+            hipLaunchKernelGGL(gen_mode_solve_kernel<T>, dim3(gb), dim3(64), 0, st, cur, out, F, ldf, dense ? 1 : 0, (int)A, s_, (int)B);
+        } else {
+            const unsigned gb = (unsigned)std::min<int64_t>((numel + 255) / 256, 4096);
+            hipLaunchKernelGGL(gen_mode_apply_kernel<T>, dim3(gb), dim3(256), 0, st, cur, out, F, ldf, dense ? 1 : 0, (int)A, s_, (int)B,
+                               last ? sumsq : (float*)nullptr, what == 1 ? 1 : 0);
+        }
         cur = out;
         A *= s_;
     }
@@ -236,6 +245,7 @@ static void layout_arenas(psgdk_plan* P) {
     for (auto& g : P->gd) {
         const size_t nb = align256((size_t)P->td[g.tensor].numel * esz);
         g.pp_off[0] = wo; wo += nb; g.pp_off[1] = wo; wo += nb;
+        if (P->geometry == PSGDK_GEOM_EQ) { g.pp2_off[0] = wo; wo += nb; g.pp2_off[1] = wo; wo += nb; }
     }
     P->work_bytes = align256(wo);
 }
@@ -384,7 +394,6 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
     if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QEP) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
-    if (geometry == PSGDK_GEOM_EQ && !plan->gd.empty()) return PSGDK_ERR_UNSUPPORTED;   // N-D tensors: Q0.5EQ1.5 only
     plan->geometry = geometry;
     layout_arenas(plan);
     return PSGDK_OK;
@@ -632,10 +641,14 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             GemmProblem g{};
             g.M = g.N = F.dp; g.K = K; g.lda = g.ldb = K; g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
             if (F.slab_off) { g.flags |= GF_SPLITK; g.kchunk = 3072; g.slab = (float*)(W + F.slab_off); }
+            if (D.kind == TK_GEN) { P->e_gram_prob[f] = -1; goto eq_qupd; }      // N-D tensors: Grams by kernels_gen.hiph
             P->e_gram_prob[f] = (int)P->e_g1.probs.size();
+            {
             GemmProblem g1 = g; g1.A = g1.B = W + (F.is_row ? D.pg_off : D.pgt_off); g1.C = g1.Ct = W + F.t1_off;
             GemmProblem g2 = g; g2.A = g2.B = W + (F.is_row ? D.bb_off : D.bt_off); g2.C = g2.Ct = W + F.rq_off;
             P->e_g1.probs.push_back(g1); P->e_g2.probs.push_back(g2);
+            }
+        eq_qupd:
             // Q' = Q - mu triu(term1 - term2) Q  (psgd.py:316)
             GemmProblem q{};
             q.A = W + F.r_off; q.B = S + F.qt_off; q.C = W + F.qn_off; q.Ct = W + F.qtn_off;
@@ -1027,12 +1040,41 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(eq_diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
                                          P->d_tiles_diag, P->state, P->work));
+    // N-D tensors: A and B mode by mode (two ping-pong pairs), then every mode's two Grams
+    for (const GenDesc& g : P->gd) {
+        const TensorDesc& D = P->td[g.tensor];
+        DISPATCH_T(P, {
+            const T* At = gen_apply_chain<T>(P, g, (const T*)(P->work + D.x_off), (T*)nullptr, (float*)nullptr, st, 1, 0);
+            const T* Bt = gen_apply_chain<T>(P, g, (const T*)(P->work + D.v_off), (T*)nullptr, (float*)nullptr, st, 2, 1);
+            int64_t A = 1;
+            for (int i = 0; i < g.ndim; ++i) {
+                const int s_ = g.dims[i];
+                const int64_t B = D.numel / (A * s_);
+                if (g.fkind[i] == PSGDK_DENSE) {
+                    const DenseDesc& Fd = P->dn[g.fidx[i]];
+                    const dim3 gg(s_, (s_ + 63) / 64);
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, gg, dim3(256), 0, st, At, (int)A, s_, (int)B, 1, (T*)(P->work + Fd.t1_off), Fd.dp,
+                                       (float*)nullptr);
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, gg, dim3(256), 0, st, Bt, (int)A, s_, (int)B, 1, (T*)(P->work + Fd.rq_off), Fd.dp,
+                                       (float*)nullptr);
+                } else {
+                    const DiagDesc& Gd = P->dd[g.fidx[i]];
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, 1), dim3(256), 0, st, At, (int)A, s_, (int)B, 0, (T*)nullptr, 0,
+                                       (float*)(P->work + Gd.sum_off));
+                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, 1), dim3(256), 0, st, Bt, (int)A, s_, (int)B, 0, (T*)nullptr, 0,
+                                       (float*)(P->work + Gd.sum2_off));
+                }
+                A *= s_;
+            }
+        });
+    }
     if (F) {
         // term1, term2 (psgd.py:306-307)
         for (int which = 0; which < 2; ++which) {
             Stage& G = which ? P->e_g2 : P->e_g1;
             launch_stage(P, G, st);
             for (unsigned f = 0; f < F; ++f) {
+                if (P->e_gram_prob[f] < 0) continue;
                 const GemmProblem& g = G.probs[P->e_gram_prob[f]];
                 if (!(g.flags & GF_SPLITK)) continue;
                 const DenseDesc& D = P->dn[f];

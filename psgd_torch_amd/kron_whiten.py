@@ -5,7 +5,7 @@ lr_preconditioner, betaL, damping, momentum, grad_clip_max_amps, preconditioner_
 update_preconditioner_first; cf. misc/gpt2.py:440, misc/vit.py:362-363) and the same step(closure) protocol, so that
 scripts such as misc/gpt2.py / misc/vit.py / rnn_xor_problem_general_purpose_preconditioner.py can switch by changing
 the import.  Built geometries: dQ = "Q0.5EQ1.5" (the reference's default and recommended choice, psgd.py:10-12),
-"QEQ", "QUAD", "QEP", and "EQ" (the triangular one, psgd.py:278-336; tensors with at most two non-singleton dims).
+"QEQ", "QUAD", "QEP", and "EQ" (the triangular one, psgd.py:278-336).
 """
 from __future__ import annotations
 
