@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-apply-only", action="store_true", help="skip the secondary apply-only measurement (profiling runs)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
@@ -275,7 +276,7 @@ def main():
     # secondary figure: the apply-only step, i.e. the steady state once the update probability is annealed down
     # (momentum + precondition + clip + parameter update; the preconditioner update gated off).  Outside the timed region.
     apply_only_ms = None
-    if not dist:
+    if not dist and not args.no_apply_only:
         for g in opt.param_groups:
             g["preconditioner_update_probability"] = 1e-12
         for i in range(3):
