@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whiten-grad", action="store_true", help="variant: fit P on the gradient, apply it to the momentum "
+                                                               "(KWNS4(whiten_grad=True)); the headline uses the default False")
     ap.add_argument("--no-apply-only", action="store_true", help="skip the secondary apply-only measurement (profiling runs)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
@@ -210,7 +212,8 @@ def main():
 
     def make(shard):
         ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
-        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, shard_state=shard)   # reference defaults otherwise
+        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, shard_state=shard,
+                                        whiten_grad=args.whiten_grad)                     # reference defaults otherwise
 
     def step_of(ps, o):
         def f(i):
@@ -308,7 +311,8 @@ def main():
                                               f"{nparam} params, 62 dense 768x768 Kron factors",
                                 "gpt2-medium": f"GPT-2-medium parameter shapes (24 layers, d=1024): {len(shapes)} tensors, {nparam} params",
                                 "lenet5": f"LeNet5 parameter shapes (mnist_with_lenet5.py): 5 tensors, {nparam} params, fp32"}[args.config]
-                               + "; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)",
+                               + ("; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)" if not args.whiten_grad
+                                  else "; KWNS4 defaults except whiten_grad=True (momentum 0.9, update probability 1, max_skew 1)"),
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
                    "parallelism": "single GPU" if world == 1 else (f"per-parameter state sharding x{world} + one all-gather per step"
                                                                    if mode == "sharded" else f"replicas x{world} (no exchange step)"),
