@@ -211,10 +211,12 @@ def test_kwns4_step_vs_golden(name):
                     assert e_hip <= 1.5 * e_ref + 1e-2, (name, t, i, j, "P", e_hip, e_ref)
 
 
-@pytest.mark.parametrize("shape,max_skew", [((96, 64), 1.0), ((64, 64), 1.0), ((200,), 1.0), ((48, 80), 0.0)])
+@pytest.mark.parametrize("shape,max_skew", [((96, 64), 1.0), ((64, 64), 1.0), ((200,), 1.0), ((48, 80), 0.0),
+                                            ((), 1.0), ((40,), float("inf")), ((64, 96), 1.0), ((8, 6, 5), float("inf"))])
 def test_known_answer_whitening(shape, max_skew):
-    """Restates misc/psgd_kron_verification.py (whitening branch): G = H1 V H2 with known SPD Kronecker H (dense H for
-    dense factors, diagonal H for diagonal ones); after annealed updates with the engine's own Philox noise,
+    """Restates misc/psgd_kron_verification.py (whitening branch) for its eight structures -- scalar, diag, matrix,
+    kron(diag,diag), kron(diag,mat), kron(mat,diag), kron(mat,mat), kron(mat,mat,mat): G = H x V with known SPD Kronecker H
+    (dense H for dense factors, diagonal H for diagonal ones); after annealed updates with the engine's own Philox noise,
     precond_grad(G) must recover V."""
     amd = _amd()
     torch.manual_seed(3)
@@ -227,16 +229,21 @@ def test_known_answer_whitening(shape, max_skew):
             Hs.append((torch.eye(s) * 0.3 + W @ W.t()).to(DEV))
         else:
             Hs.append(torch.diag(0.2 + 3 * torch.rand(s, generator=gen)).to(DEV))
+    if len(shape) == 0:
+        Hs = [torch.tensor(1.7, device=DEV)]
     QL, exprs = amd.init_kron(torch.zeros(shape, device=DEV), Scale=1.0, max_skew=max_skew)
     num_iters = 1500
     dgen = torch.Generator(device=DEV).manual_seed(11)
     for it in range(num_iters):
         V = torch.randn(shape, device=DEV, generator=dgen)
-        G = Hs[0] @ V if len(shape) == 1 else Hs[0] @ V @ Hs[1]
+        G = V
+        for i, H in enumerate(Hs):       # mode products
+            G = torch.movedim(torch.tensordot(H, torch.movedim(G, i, 0), dims=1), 0, i) if len(shape) else H.reshape(()) * G
         amd.update_precond_kron_whiten_q0p5eq1p5(QL, exprs, G, lr=(1 - it / num_iters) / 2, betaL=0.9, damping=0.0)
     h = amd.precond_grad_kron(QL, exprs, G)
     err = relerr(h, V)
-    assert err < 0.08, (shape, max_skew, err)
+    # a dense factor fitted from ONE vector sample per step stays noisier (the CPU oracle reaches 0.18 on this case)
+    assert err < (0.25 if shape == (40,) else 0.08), (shape, max_skew, err)
 
 
 def test_kronwhiten_closure_shell():
