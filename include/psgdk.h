@@ -178,6 +178,16 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
 int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,
                             float max_elem_amp, void* stream);
 
+/* ---- the exchange step of the sharded (N > 1) path.  After the all-gather of the clipped preconditioned gradients every rank
+ * applies p <- p (1 - decoupled_wd lr) - lr h (..._ddp.py:120,157) to ALL n tensors in one launch, reading h from the flat
+ * exchange buffer (tensor t at element offset h_offset[t], numel[t] elements, dtype h_dtype; offsets that are multiples of
+ * 8 take the 16-byte path).  New relative to the reference, which runs replicas only. */
+typedef struct psgdk_flat psgdk_flat;
+int psgdk_flat_create(psgdk_flat** out, int n, const int64_t* numel, const int64_t* h_offset);
+int psgdk_flat_destroy(psgdk_flat* flat);
+int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                     float decoupled_wd, void* stream);
+
 /* fill `out` with the engine's N(0,1) stream (same generator the fused kernels use), for statistical tests. */
 int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
                       void* stream);

@@ -1150,6 +1150,51 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
     return PSGDK_OK;
 }
 
+// ---- the exchange step of the sharded path: parameter update of ALL tensors from the gathered flat h ---------------------
+struct psgdk_flat {
+    int n = 0;
+    FlatDesc* d_fd = nullptr; FlatChunk* d_chunks = nullptr; unsigned n_chunks = 0;
+    void** d_ptrs = nullptr;
+    std::vector<const void*> h_ptrs;
+    ~psgdk_flat() { if (d_fd) (void)hipFree(d_fd); if (d_chunks) (void)hipFree(d_chunks); if (d_ptrs) (void)hipFree(d_ptrs); }
+};
+
+int psgdk_flat_create(psgdk_flat** out, int n, const int64_t* numel, const int64_t* h_offset) {
+    if (!out || n <= 0 || !numel || !h_offset) return PSGDK_ERR_INVALID;
+    std::unique_ptr<psgdk_flat> F(new psgdk_flat());
+    F->n = n;
+    std::vector<FlatDesc> fd(n);
+    std::vector<FlatChunk> ck;
+    for (int t = 0; t < n; ++t) {
+        if (numel[t] < 0 || h_offset[t] < 0 || numel[t] > 0x7fffffffLL) return PSGDK_ERR_INVALID;
+        fd[t] = FlatDesc{(long long)numel[t], (long long)h_offset[t]};
+        for (int64_t s0 = 0; s0 < numel[t]; s0 += 2048) ck.push_back(FlatChunk{t, (int)s0});
+    }
+    F->n_chunks = (unsigned)ck.size();
+    int rc;
+    if ((rc = upload(&F->d_fd, fd)) || (rc = upload(&F->d_chunks, ck))) return rc;
+    HIPCHK(hipMalloc((void**)&F->d_ptrs, (size_t)n * sizeof(void*)));
+    *out = F.release();
+    return PSGDK_OK;
+}
+
+int psgdk_flat_destroy(psgdk_flat* flat) { delete flat; return PSGDK_OK; }
+
+int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                     float decoupled_wd, void* stream) {
+    if (!flat || !params || !h_flat || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32) ||
+        (h_dtype != PSGDK_BF16 && h_dtype != PSGDK_F32) || !(lr > 0.f) || !(decoupled_wd >= 0.f)) return PSGDK_ERR_INVALID;
+    for (int t = 0; t < flat->n; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, (const void* const*)params, flat->n, st))) return rc;
+    if (flat->n_chunks)
+        hipLaunchKernelGGL(flat_apply_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks, (void* const*)flat->d_ptrs,
+                           param_dtype, h_flat, h_dtype, lr, 1.0f - decoupled_wd * lr);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
 int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,
                             float max_elem_amp, void* stream) {
     if (!plan || t < 0 || t >= plan->n_tensors || !out || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;

@@ -15,7 +15,41 @@ import torch
 from . import _lib as L
 
 
+class FlatApply:
+    """psgdk_flat_*: the parameter update of the sharded path's exchange step (all tensors, one launch)."""
+
+    def __init__(self, numels: Sequence[int], offsets: Sequence[int], device):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, "FlatApply needs a ROCm device (cuda:N); there is no CPU fallback")
+        self.n = len(numels)
+        self._h = C.c_void_p()
+        na = (C.c_int64 * self.n)(*[int(x) for x in numels])
+        oa = (C.c_int64 * self.n)(*[int(x) for x in offsets])
+        L.check(self.lib.psgdk_flat_create(C.byref(self._h), self.n, na, oa), "flat_create")
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.psgdk_flat_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def apply(self, params: Sequence[torch.Tensor], flat: torch.Tensor, lr: float, decoupled_wd: float):
+        pa = L.ptr_array(params)
+        self._keep = (pa, list(params), flat)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(self.lib.psgdk_flat_apply(self._h, pa, L.dtype_code(params[0].dtype), flat.data_ptr(), L.dtype_code(flat.dtype),
+                                          float(lr), float(decoupled_wd), st), "flat_apply")
+
+
 class KronEngine:
+    FlatApply = FlatApply
+
     def __init__(self, shapes: Sequence[Sequence[int]], device, precond_dtype=torch.bfloat16, max_size=float("inf"),
                  max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0,
                  tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5"):

@@ -33,8 +33,7 @@ class _Bucket:
         self.owned: List[int] = []          # indices into params this rank preconditions
         self.step = 0
         self.flat = None                     # sharded mode: gathered clipped h
-        self.flat_cast = None                # ... and its copy in the parameter dtype
-        self.h_cast_views = None
+        self.flat_apply = None               # fused parameter update from the gathered buffer
         self.segments = None
 
 
@@ -228,18 +227,23 @@ class KWNS4(torch.optim.Optimizer):
         for p in plist:
             self.state[p]["step"] = 0
         if self.shard_state:
-            # flat exchange buffer: equal-size (padded) segment per rank, in owner order
+            # flat exchange buffer: equal-size (padded) segment per rank, in owner order; every tensor starts at a multiple of 8
+            # elements so that the fused parameter update reads it with 16-byte accesses
             numels = [math.prod(s) if len(s) else 1 for s in shapes]
-            per_rank = [sum(numels[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
-            seg = max(per_rank + [1])
+            pad8 = [(n + 7) // 8 * 8 for n in numels]
+            per_rank = [sum(pad8[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
+            seg = max(per_rank + [8])
             b.seg = seg
             b.flat = torch.zeros(self.world * seg, dtype=pd, device=p0.device)
             offs = [r * seg for r in range(self.world)]
-            b.h_views = []
+            b.h_views, h_offsets = [], []
             for i, s in enumerate(shapes):
                 r = owner[i]
                 b.h_views.append(b.flat[offs[r]:offs[r] + numels[i]].view(s))
-                offs[r] += numels[i]
+                h_offsets.append(offs[r])
+                offs[r] += pad8[i]
+            # p <- p (1 - wd lr) - lr h for all tensors from the gathered buffer: one launch (engine-provided)
+            b.flat_apply = self._engine_factory.FlatApply(numels, h_offsets, p0.device)
         self._buckets[key] = b
         pending = getattr(self, "_pending_restore", None)
         if pending:                      # load_state_dict() was called before the buckets existed
@@ -306,18 +310,7 @@ class KWNS4(torch.optim.Optimizer):
             mine = b.flat[self.rank * b.seg:(self.rank + 1) * b.seg]
             torch.distributed.all_gather_into_tensor(b.flat, mine.clone())
             lps = [self._data_of(p) for p in plist]
-            if wd > 0.0 and decoupled:
-                torch._foreach_mul_(lps, 1.0 - wd * lr)                               # ..._ddp.py:120
-            if b.flat.dtype != lps[0].dtype:
-                # one cast of the whole exchange buffer (not one per tensor), then a multi-tensor update
-                if b.flat_cast is None:
-                    b.flat_cast = torch.empty_like(b.flat, dtype=lps[0].dtype)
-                    b.h_cast_views = [b.flat_cast[v.storage_offset():v.storage_offset() + v.numel()].view(v.shape) for v in b.h_views]
-                b.flat_cast.copy_(b.flat)
-                hs = [h.view_as(p) for h, p in zip(b.h_cast_views, lps)]
-            else:
-                hs = [h.view_as(p) for h, p in zip(b.h_views, lps)]
-            torch._foreach_add_(lps, hs, alpha=-lr)                                   # ..._ddp.py:157
+            b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
         b.step += 1
         for p in plist:
             self.state[p]["step"] += 1

@@ -13,7 +13,22 @@ from oracle import psgd_oracle as orc
 SRC_EMA, SRC_GRAD = 0, 1
 
 
+class _TorchFlatApply:
+    """TEST-ONLY counterpart of psgd_torch_amd.engine.FlatApply on CPU tensors."""
+
+    def __init__(self, numels, offsets, device):
+        self.numels, self.offsets = list(numels), list(offsets)
+
+    def apply(self, params, flat, lr, decoupled_wd):
+        for p, n, o in zip(params, self.numels, self.offsets):
+            if decoupled_wd:
+                p.mul_(1.0 - decoupled_wd * lr)
+            p.subtract_(flat[o:o + n].view_as(p).to(p.dtype), alpha=lr)
+
+
 class OracleEngine:
+    FlatApply = _TorchFlatApply
+
     def __init__(self, shapes, device, precond_dtype=torch.bfloat16, max_size=float("inf"), max_skew=1.0,
                  use_momentum=True, init_scale=1.0, tensor_ids=None):
         self.shapes = [tuple(s) for s in shapes]
