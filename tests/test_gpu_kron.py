@@ -372,3 +372,42 @@ def test_kwns4_split_on_changing_gradient_set():
     for a, b in zip(pa[:-1], pb[:-1]):
         assert relerr(b.data, a.data) <= 1e-5, relerr(b.data, a.data)
         assert ob.state[b]["step"] == 5
+
+
+def test_kwns4_bf16_parameters_and_gradients():
+    """Parameters and gradients held in bf16 (the dtype misc/gpt2.py trains in): the engine reads/writes them in place;
+    trajectory vs the oracle's restatement of the reference loop on bf16 tensors with replayed noise."""
+    amd = _amd()
+    shapes = [(48, 32), (32,), (24, 24), (1, 16, 1)]
+    gen = torch.Generator().manual_seed(21)
+    p_cpu = [(0.5 * torch.randn(s, generator=gen)).to(torch.bfloat16) for s in shapes]
+    params = [torch.nn.Parameter(p.clone().to(DEV)) for p in p_cpu]
+    kw = dict(preconditioner_dtype=torch.bfloat16, lr_params=1e-2, weight_decay=0.01)
+    opt = amd.KWNS4(params, **kw)
+    cur = {}
+
+    def noise_for(G, kinds):
+        n = orc.KronNoise.draw(G, kinds, gen)
+        cur.setdefault("list", []).append(n)
+        return n
+    ref_p = [p.clone() for p in p_cpu]
+    oracle = orc.KWNS4Oracle(ref_p, uniform=lambda: 0.0, noise_for=noise_for, **kw)
+    for step in range(4):
+        grads = [(0.3 * torch.randn(s, generator=gen)).to(torch.bfloat16) for s in shapes]
+        cur["list"] = []
+        oracle.step([g.clone() for g in grads])
+        per = cur["list"]
+
+        def replay(b, plist, per=per):
+            g = [per[i].g_noise.to(DEV) for i in b.owned]
+            spd = {(k, j): x.to(DEV) for k, i in enumerate(b.owned) for j, x in enumerate(per[i].spd) if x is not None}
+            skh = {(k, j): x.to(DEV) for k, i in enumerate(b.owned) for j, x in enumerate(per[i].skh) if x is not None}
+            return dict(noise=(g, spd, skh), balance_mask=[per[i].balance_u < 0.01 for i in b.owned])
+        opt._uniform = lambda: 0.0
+        opt._replay = replay
+        for p, g in zip(params, grads):
+            p.grad = g.to(DEV)
+        opt.step()
+    for p, q in zip(params, ref_p):
+        assert p.dtype == torch.bfloat16
+        assert relerr(p.detach().float(), q.float()) <= 2e-2, relerr(p.detach().float(), q.float())
