@@ -15,6 +15,20 @@ import torch
 from . import _lib as L
 
 
+def _on_device(fn):
+    """Run an engine call with the engine's GPU current: the library launches on the stream it is handed, and HIP requires
+    that stream's device to be the calling thread's current device (torch ops follow their tensors; raw launches do not)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class FlatApply:
     """psgdk_flat_*: the parameter update of the sharded path's exchange step (all tensors, one launch)."""
 
@@ -65,6 +79,8 @@ class KronEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.PsgdkError(L.PSGDK_ERR_INVALID, "KronEngine needs a ROCm device (cuda:N); there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = precond_dtype
         self.code = L.dtype_code(precond_dtype)
         self.shapes = [tuple(int(x) for x in s) for s in shapes]
@@ -160,12 +176,15 @@ class KronEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @_on_device
     def init_state(self, scale: float):
         L.check(self.lib.psgdk_init_state(self._plan, float(scale), self._stream()), "init_state")
 
+    @_on_device
     def state_changed(self):
         L.check(self.lib.psgdk_state_changed(self._plan, self._stream()), "state_changed")
 
+    @_on_device
     def accumulate(self, grads: Sequence[torch.Tensor], params: Optional[Sequence[torch.Tensor]] = None,
                    coupled_wd: float = 0.0, beta: float = 0.0, keep_grad: bool = False, damp: Optional[dict] = None):
         """damp = dict(source, damping, seed, offset): fuse the damped input of an update_precond call that will follow
@@ -186,6 +205,7 @@ class KronEngine:
         L.check(self.lib.psgdk_accumulate(self._plan, ga, L.dtype_code(grads[0].dtype), pa, pdt, float(coupled_wd),
                                           float(beta), int(keep_grad), dp, self._stream()), "accumulate")
 
+    @_on_device
     def update_precond(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0,
                        noise=None, balance_mask: Optional[Sequence[bool]] = None):
         """noise: None (Philox) or (g_noise list[n], spd dict{(t,i): tensor}, skh dict{(t,i): tensor}).
@@ -221,9 +241,11 @@ class KronEngine:
                    self._stream()), "update_precond")
         self._keep_noise = keep
 
+    @_on_device
     def precond_grad(self, source: int):
         L.check(self.lib.psgdk_precond_grad(self._plan, int(source), self._stream()), "precond_grad")
 
+    @_on_device
     def apply_update(self, params: Sequence[torch.Tensor], lr: float, decoupled_wd: float, max_avg_amp: float,
                      max_elem_amp: float):
         pa = L.ptr_array(params)
@@ -231,6 +253,7 @@ class KronEngine:
         L.check(self.lib.psgdk_apply_update(self._plan, pa, L.dtype_code(params[0].dtype), float(lr), float(decoupled_wd),
                                             float(max_avg_amp), float(max_elem_amp), self._stream()), "apply_update")
 
+    @_on_device
     def read_precond_grad(self, t: int, out: Optional[torch.Tensor] = None, clip: bool = False, max_avg_amp: float = 2.0,
                           max_elem_amp: float = 10.0) -> torch.Tensor:
         if out is None:
@@ -243,6 +266,7 @@ class KronEngine:
     def profile_enable(self, on: bool = True):
         L.check(self.lib.psgdk_profile_enable(self._plan, int(on)), "profile_enable")
 
+    @_on_device
     def profile_read(self, reset: bool = True):
         ms, n = C.c_double(), C.c_int64()
         L.check(self.lib.psgdk_profile_read(self._plan, C.byref(ms), C.byref(n), int(reset)), "profile_read")

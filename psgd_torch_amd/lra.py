@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from .engine import _on_device
 
 
 class _LraEngine:
@@ -36,6 +37,7 @@ class _LraEngine:
         L.check(self.lib.psgdk_lra_work_bytes(self.h, C.byref(wb)), "lra_work_bytes")
         self.work = torch.zeros(wb.value, dtype=torch.uint8, device=d.device)
         self.keep = (U, V, d, Luvd3)
+        self.device = d.device if d.device.index is not None else torch.device("cuda", torch.cuda.current_device())
         L.check(self.lib.psgdk_lra_bind(self.h, U.data_ptr() if self.r else None, V.data_ptr() if self.r else None, d.data_ptr(),
                                         Luvd3.data_ptr(), self.work.data_ptr()), "lra_bind")
 
@@ -50,6 +52,7 @@ class _LraEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.keep[2].device).cuda_stream)
 
+    @_on_device
     def update_whiten(self, g, lr, betaL, damping, v_noise=None, seed=0, offset=0, update_u=True):
         g = g.contiguous()
         vn = v_noise.to(g.dtype).contiguous() if v_noise is not None else None
@@ -58,6 +61,7 @@ class _LraEngine:
                                                  int(offset), int(bool(update_u)), float(lr), float(betaL), float(damping),
                                                  self._stream()), "lra_update_whiten")
 
+    @_on_device
     def precond_grad(self, g):
         g = g.contiguous()
         out = torch.empty_like(g)
