@@ -4,14 +4,14 @@
 A "step" is ONE full KWNS4.step() over all 148 parameter tensors of GPT-2-small (124,475,904 params): coupled work
 of wrapped_as_torch_optimizer_for_ddp.py:98-176 -- momentum EMA, preconditioner update (probability 1) with the
 Q0.5EQ1.5 geometry, preconditioning, clipping, parameter update -- with bf16 preconditioner state, fp32 parameters and
-synthetic fp32 gradients already resident in HBM.  N > 1: preconditioner state is sharded per parameter across the
-ranks (shard_state=True) and the clipped preconditioned gradients are exchanged with one all-gather; total work is
-fixed, so scaling is "strong".
+synthetic fp32 gradients already resident in HBM.  N > 1: either preconditioner state sharded per parameter across the
+ranks (shard_state=True; the clipped preconditioned gradients are exchanged with one all-gather) or plain replicas --
+--parallelism auto (default) times both in warm-up and keeps the faster; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
-  roofline     -- for the dominant kernel (the grouped NT MFMA GEMM): algorithmic FLOPs of the GEMM launches of a step
-                  (SURVEY 8d model, minus the subspace-iteration term which runs in another kernel) / their launch time
-                  measured live with hipEvents on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  roofline     -- for the dominant kernel (the grouped NT MFMA GEMM, both tilings): algorithmic FLOPs of a step (SURVEY 8d
+                  model, 905.2 GFLOP, all of it in the 17 GEMM launches) / their launch time measured live with hipEvents
+                  on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
   cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -20,6 +20,8 @@ import math
 import os
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL / multi-process)
 
 import torch
 
