@@ -1,0 +1,73 @@
+"""Randomised differential test of the HIP path against the CPU oracle (fp32, explicit noise): random shapes (odd sizes,
+singleton dims, 0..4 dims), dense/diagonal decisions (max_skew, max_size), all five built geometries, a few steps each.
+Catches layout / edge-tile / padding mistakes the fixed golden shapes may miss; the oracle is pinned to the reference by
+tests/test_oracle_golden.py."""
+import random
+
+import pytest
+import torch
+
+from helpers import P_of, relerr
+from oracle import psgd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+GEOMS = ["Q0.5EQ1.5", "EQ", "QEQ", "QUAD", "QEP"]
+
+
+def _case(seed):
+    rnd = random.Random(seed)
+    nd = rnd.choice([0, 1, 1, 2, 2, 2, 2, 3, 4])
+    if nd <= 2:
+        shape = tuple(rnd.choice([1, 2, 3, 7, 16, 33, 63, 64, 65, 100, 129, 200, 257]) for _ in range(nd))
+    else:
+        shape = tuple(rnd.choice([1, 2, 3, 5, 8, 12]) for _ in range(nd))
+    max_skew = rnd.choice([0.0, 0.5, 1.0, 2.0, float("inf")])
+    max_size = rnd.choice([float("inf"), float("inf"), 20.0, 100.0])
+    geom = rnd.choice(GEOMS)
+    return shape, max_skew, max_size, geom
+
+
+import os  # noqa: E402
+
+N_CASES = int(os.environ.get("PSGDK_FUZZ_CASES", "40"))        # raise for a longer hunt (e.g. PSGDK_FUZZ_CASES=1000)
+
+
+@pytest.mark.parametrize("seed", list(range(N_CASES)))
+def test_random_case_matches_oracle(seed):
+    import psgd_torch_amd as amd
+    shape, max_skew, max_size, geom = _case(seed)
+    sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
+    upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
+               "QEQ": amd.update_precond_kron_whiten_qeq, "QUAD": amd.update_precond_kron_whiten_quad,
+               "QEP": amd.update_precond_kron_whiten_qep}[geom]
+    upd_orc = {"Q0.5EQ1.5": orc.update_precond_kron_whiten_q0p5eq1p5, "EQ": orc.update_precond_kron_whiten_eq,
+               "QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
+               "QEP": orc.update_precond_kron_whiten_qep}[geom]
+    gen = torch.Generator().manual_seed(1000 + seed)
+    kw = dict(Scale=0.7, max_size=max_size, max_skew=max_skew)
+    QL, exprs = amd.init_kron(torch.zeros(sq, device=DEV), dQ=geom, **kw)
+    QLo, kinds = orc.init_kron(torch.zeros(sq), **kw)
+    assert [q.dim() == 2 for q in QL[0]] == [k == "dense" for k in kinds], (shape, kinds)
+    for t in range(3):
+        G = 0.5 * torch.randn(sq, generator=gen)
+        nz = orc.KronNoise.draw(G, kinds, gen)
+        nz.balance_u = 0.0 if t == 1 else 1.0                  # exercise the balancing branch once
+        dev_noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd) if x is not None},
+                     {(0, i): x.to(DEV) for i, x in enumerate(nz.skh) if x is not None})
+        kwargs = dict(lr=0.2, betaL=0.9, damping=1e-6, noise=dev_noise)
+        if geom != "QEP":
+            kwargs["balance"] = nz.balance_u < 0.01
+        upd_amd(QL, exprs, G.to(DEV), **kwargs)
+        upd_orc(QLo, G, nz, lr=0.2, betaL=0.9, damping=1e-6)
+        h = amd.precond_grad_kron(QL, exprs, G.to(DEV))
+        ho = orc.precond_grad_kron(QLo[0], G)
+        tag = (seed, shape, max_skew, max_size, geom, t)
+        assert relerr(h, ho) <= 2e-4, tag + ("h", relerr(h, ho))
+        for i in range(len(QL[0])):
+            if geom == "Q0.5EQ1.5":                            # Q is gauge dependent there (Procrustes on rounding noise)
+                assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= 2e-4, tag + (i, "P")
+            else:
+                assert relerr(QL[0][i], QLo[0][i]) <= 2e-4, tag + (i, "Q")
+            assert relerr(QL[1][i], QLo[1][i]) <= 2e-4, tag + (i, "L")
