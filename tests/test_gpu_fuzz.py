@@ -71,3 +71,56 @@ def test_random_case_matches_oracle(seed):
             else:
                 assert relerr(QL[0][i], QLo[0][i]) <= 2e-4, tag + (i, "Q")
             assert relerr(QL[1][i], QLo[1][i]) <= 2e-4, tag + (i, "L")
+
+
+M_CASES = int(os.environ.get("PSGDK_FUZZ_KWNS4", "12"))
+
+
+@pytest.mark.parametrize("seed", list(range(M_CASES)))
+def test_random_kwns4_configuration_matches_oracle_loop(seed):
+    """The batched optimizer (several tensors of random shapes in ONE engine, random hyper-parameters) against the oracle's
+    restatement of the reference loop (wrapped_as_torch_optimizer_for_ddp.py:98-176), noise replayed, fp32."""
+    import psgd_torch_amd as amd
+    rnd = random.Random(5000 + seed)
+    n = rnd.randint(2, 7)
+    shapes = []
+    for _ in range(n):
+        nd = rnd.choice([0, 1, 2, 2, 2, 3])
+        shapes.append(tuple(rnd.choice([1, 3, 8, 17, 40, 64, 70, 130] if nd <= 2 else [1, 2, 4, 6]) for _ in range(nd)))
+    momentum = rnd.choice([0.0, 0.9, 0.5])
+    kw = dict(preconditioner_dtype=torch.float32, lr_params=1e-2, lr_preconditioner=rnd.choice([0.1, 0.5]),
+              momentum=momentum, whiten_grad=(rnd.random() < 0.5) or momentum == 0.0,
+              weight_decay=rnd.choice([0.0, 0.05]), decoupled_weight_decay=rnd.random() < 0.5,
+              update_preconditioner_first=rnd.random() < 0.5, preconditioner_max_skew=rnd.choice([1.0, 2.0, float("inf")]),
+              preconditioner_max_size=rnd.choice([float("inf"), 50.0]), preconditioner_init_scale=rnd.choice([1.0, 0.3]),
+              grad_clip_max_amps=rnd.choice([(2.0, 10.0), (1.0, 1.5)]))
+    gen = torch.Generator().manual_seed(6000 + seed)
+    p_cpu = [0.3 * torch.randn(s, generator=gen) for s in shapes]
+    params = [torch.nn.Parameter(p.clone().to(DEV)) for p in p_cpu]
+    opt = amd.KWNS4(params, **kw)
+    cur = {}
+
+    def noise_for(G, kinds):
+        nz = orc.KronNoise.draw(G, kinds, gen)
+        cur.setdefault("list", []).append(nz)
+        return nz
+    ref_p = [p.clone() for p in p_cpu]
+    oracle = orc.KWNS4Oracle(ref_p, uniform=lambda: 0.0, noise_for=noise_for, **kw)
+    for step in range(3):
+        grads = [0.4 * torch.randn(s, generator=gen) for s in shapes]
+        cur["list"] = []
+        oracle.step([g.clone() for g in grads])
+        per = cur["list"]
+
+        def replay(b, plist, per=per):
+            g = [per[i].g_noise.to(DEV) for i in b.owned]
+            spd = {(k, j): x.to(DEV) for k, i in enumerate(b.owned) for j, x in enumerate(per[i].spd) if x is not None}
+            skh = {(k, j): x.to(DEV) for k, i in enumerate(b.owned) for j, x in enumerate(per[i].skh) if x is not None}
+            return dict(noise=(g, spd, skh), balance_mask=[per[i].balance_u < 0.01 for i in b.owned])
+        opt._uniform = lambda: 0.0
+        opt._replay = replay
+        for p, g in zip(params, grads):
+            p.grad = g.to(DEV)
+        opt.step()
+    for i, (p, q) in enumerate(zip(params, ref_p)):
+        assert relerr(p.detach(), q) <= 1e-4, (seed, shapes, kw, i, relerr(p.detach(), q))
