@@ -124,3 +124,39 @@ def test_random_kwns4_configuration_matches_oracle_loop(seed):
         opt.step()
     for i, (p, q) in enumerate(zip(params, ref_p)):
         assert relerr(p.detach(), q) <= 1e-4, (seed, shapes, kw, i, relerr(p.detach(), q))
+
+
+L_CASES = int(os.environ.get("PSGDK_FUZZ_LRA", "12"))
+
+
+@pytest.mark.parametrize("seed", list(range(L_CASES)))
+def test_random_lra_case_matches_oracle(seed):
+    """LRA update + apply with random N (ragged against the 256-row blocks), rank 0..16, both update branches; fp32."""
+    from psgd_torch_amd import lra
+    rnd = random.Random(9000 + seed)
+    N = rnd.choice([1, 2, 17, 255, 256, 257, 511, 1000, 2049, 5000])
+    r = min(rnd.choice([0, 1, 2, 5, 10, 16]), max(N - 1, 0))
+    gen = torch.Generator().manual_seed(9100 + seed)
+    U = torch.randn(N, r, generator=gen); V = torch.randn(N, r, generator=gen)
+    if r:
+        U = U * (0.1 ** 0.5 / torch.linalg.vector_norm(U)); V = V * (0.1 ** 0.5 / torch.linalg.vector_norm(V))
+    d = 0.5 + torch.rand(N, 1, generator=gen)
+    UVd = [U.clone().to(DEV).contiguous(), V.clone().to(DEV).contiguous(), d.clone().to(DEV).contiguous()]
+    Luvd = [torch.zeros([], device=DEV) for _ in range(3)]
+    Uo = [U.clone(), V.clone(), d.clone()]
+    Lo = [torch.zeros([]) for _ in range(3)]
+    for t in range(3):
+        g = (0.5 + 2 * torch.rand(N, 1, generator=gen)) * torch.randn(N, 1, generator=gen)
+        vn = torch.randn(N, 1, generator=gen)
+        coin = 0.25 if (t + seed) % 2 == 0 else 0.75
+        lra.update_precond_lra_whiten(UVd, Luvd, g.to(DEV), lr=0.1, betaL=0.9, damping=1e-6, v_noise=vn.to(DEV), coin=coin)
+        orc.update_precond_lra_whiten(Uo, Lo, g, vn, coin, lr=0.1, betaL=0.9, damping=1e-6)
+        h = lra.precond_grad_lra(UVd, g.to(DEV))
+        ho = orc.precond_grad_lra(Uo, g)
+        tag = (seed, N, r, t)
+        assert relerr(h, ho) <= 2e-4, tag + ("h", relerr(h, ho))
+        for k, nm in enumerate("UVd"):
+            if UVd[k].numel():
+                assert relerr(UVd[k], Uo[k]) <= 2e-4, tag + (nm, relerr(UVd[k], Uo[k]))
+        for k in range(3):
+            assert relerr(Luvd[k], Lo[k]) <= 2e-4, tag + ("L", k)
