@@ -70,13 +70,16 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 /* Optional, before psgdk_plan_arena_bytes / psgdk_plan_bind: the update geometry the plan will be driven with -- the dQ
  * argument of psgd.init_kron (psgd.py:161).  PSGDK_GEOM_Q0P5EQ1P5 (default; dense Q, psgd.py:394-419) or PSGDK_GEOM_EQ
  * (upper-triangular Q, psgd.py:278-336; needs extra work buffers), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483), PSGDK_GEOM_QEP
- * (psgd.py:339-364).  The two geometries of the reference that fit P directly (QUAD4P, PRO4P) are not built.  Each update entry point below requires the plan to
+ * (psgd.py:339-364), PSGDK_GEOM_QUAD4P (psgd.py:486-513: the factors ARE P; psgdk_precond_grad then applies every
+ * factor once, as KronWhiten does for this choice, psgd.py:573; init scale is squared by the caller like psgd.py:186-187).
+ * PRO4P is not built.  Each update entry point below requires the plan to
  * carry its geometry (else PSGDK_ERR_STATE). */
 #define PSGDK_GEOM_Q0P5EQ1P5 0
 #define PSGDK_GEOM_EQ 1
 #define PSGDK_GEOM_QEQ 2
 #define PSGDK_GEOM_QUAD 3
 #define PSGDK_GEOM_QEP 4
+#define PSGDK_GEOM_QUAD4P 5
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
@@ -147,6 +150,10 @@ int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL
 int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping,
                               const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                               const uint8_t* balance_mask, void* stream);
+/* psgd.update_precond_kron_whiten_quad4p (psgd.py:486-513): as _quad with full steps lr/L, on P itself. */
+int psgdk_update_precond_quad4p(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                                const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                                const uint8_t* balance_mask, void* stream);
 /* psgd.update_precond_kron_whiten_qep (psgd.py:339-364): balancing of every tensor FIRST and on every call (not optional,
  * psgd.py:346-347); per factor term1 = Gram_i(Q_i Pg), term2 = (numel/d) Q Q^T, ell = ||term1 + term2||_lb,
  * Q -= lr/L (term1 - term2) Q (diagonal: q *= 1 - lr/L (term1 - term2)).  No gate draw, hence no balance_mask. */

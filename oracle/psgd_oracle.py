@@ -305,6 +305,38 @@ def update_precond_kron_whiten_qep(QL, G: Tensor, noise: KronNoise, lr: float = 
             q.sub_(lr / L[i] * (term1 - term2) @ q)
 
 
+def update_precond_kron_whiten_quad4p(QL, G: Tensor, noise: KronNoise, lr: float = 0.1, betaL: float = 0.9,
+                                      damping: float = 1e-9) -> None:
+    """psgd.py:486-513: as QUAD but the factors are P itself (applied once, exprA) and the steps are full lr/L."""
+    Q, L = QL
+    total_numel = G.numel()
+    damp = damping + torch.finfo(G.dtype).eps * G.abs()
+    Pg = apply_q_kron(Q, G + damp * noise.g_noise.to(G.dtype))
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        term1 = gram_mode(Pg, i, dense)
+        if not dense:
+            term2 = total_numel / q.numel()
+            ell = torch.max(term1) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            gain = 1 - lr / L[i] * (term1 - term2)
+            q.mul_(gain * gain)
+        else:
+            term2 = total_numel / q.shape[0]
+            ell = norm_lower_bound_spd(term1, noise.spd[i]) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            p = q - lr / L[i] * (term1 @ q - term2 * q)
+            p = p - lr / L[i] * (p @ term1 - p * term2)
+            q.copy_((p + p.t()) / 2)
+    if noise.balance_u < 0.01:
+        balance_kron_precond(Q)
+
+
+def precond_grad_kron_4p(Q: List[Tensor], G: Tensor) -> Tensor:
+    """psgd.py:573: for the geometries that fit P directly the preconditioned gradient is exprA(*Q, G)."""
+    return apply_q_kron(Q, G)
+
+
 def apply_q_kron(Q: List[Tensor], X: Tensor) -> Tensor:
     """exprA (psgd.py:248-249): A = (kron_i Q_i) X, one factor per mode."""
     if X.dim() == 0:

@@ -68,6 +68,7 @@ struct psgdk_plan {
     // PSGDK_GEOM_EQ (psgd.py:278-336): A = (kron Q) Hvp in two products, Grams of A and B, Q -= mu triu(.) Q; the right
     // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
+    bool p_mode() const { return geometry == PSGDK_GEOM_QUAD4P; }      // the factors ARE P (fitted directly, psgd.py:486-513)
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
     Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
     Stage v_qep_u, v_qep_t1, v_qep_t2;               // PSGDK_GEOM_QEP: Q term1, (Q term1) Q^T, c Q Q^T
@@ -173,7 +174,7 @@ static const T* gen_apply_chain(psgdk_plan* P, const GenDesc& g, const T* src, T
         } else {
             const unsigned gb = (unsigned)std::min<int64_t>((numel + 255) / 256, 4096);
             hipLaunchKernelGGL(gen_mode_apply_kernel<T>, dim3(gb), dim3(256), 0, st, cur, out, F, ldf, dense ? 1 : 0, (int)A, s_, (int)B,
-                               last ? sumsq : (float*)nullptr, what == 1 ? 1 : 0);
+                               last ? sumsq : (float*)nullptr, (what == 1 || P->p_mode()) ? 1 : 0);
         }
         cur = out;
         A *= s_;
@@ -392,7 +393,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 }
 
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
-    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QEP) return PSGDK_ERR_INVALID;
+    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QUAD4P) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
     plan->geometry = geometry;
     layout_arenas(plan);
@@ -568,7 +569,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         GemmProblem g{};
         g.B = W + Fc.p_off; g.M = D.Rp; g.N = D.Cp; g.K = D.Cp; g.lda = D.Cp; g.ldb = Fc.dp; g.alpha = 1.f;
         if (D.kind == TK_M1) {
-            g.row_scale = rs; g.flags = rs ? GF_SQ_ROWSCALE : 0;
+            g.row_scale = rs; g.flags = (rs && !P->p_mode()) ? GF_SQ_ROWSCALE : 0;
             GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.pgt_off; u.ldct = D.Rp; u.row_sumsq = rsum; u.flags |= GF_TMAJOR;
             P->g_upd_a.probs.push_back(u);
             for (int src = 0; src < 2; ++src) {
@@ -594,7 +595,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->g_app_b.probs.push_back(ab);
         }
     }
-    if (P->geometry == PSGDK_GEOM_QEQ || P->geometry == PSGDK_GEOM_QUAD)
+    if (P->geometry == PSGDK_GEOM_QEQ || P->geometry == PSGDK_GEOM_QUAD || P->geometry == PSGDK_GEOM_QUAD4P)
         for (size_t f = 0; f < P->dn.size(); ++f) {
             const DenseDesc& F = P->dn[f];
             float* sc = (float*)(W + F.sc_off);
@@ -824,6 +825,11 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
 
 static int ensure_P(psgdk_plan* plan, hipStream_t st) {
     if (!plan->p_valid) {
+        if (plan->p_mode()) {      // P := Q (exprA applies every factor once; Q is symmetric in this geometry)
+            if (!plan->dn.empty())
+                DISPATCH_T(plan, hipLaunchKernelGGL(copy_q_to_p_kernel<T>, dim3(16, (unsigned)plan->dn.size()), dim3(256), 0, st, plan->d_dn,
+                                                    plan->state, plan->work));
+        } else
         launch_stage(plan, plan->g_P, st);
         HIPCHK(hipGetLastError());
         plan->p_valid = true;
@@ -843,6 +849,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5;
     if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || (need_skh && !noise->skh_noise))))) return PSGDK_ERR_INVALID;
     const float lr_eff = variant == PSGDK_GEOM_QUAD ? 0.5f * lr : lr;       // QUAD takes two half steps (psgd.py:473,479-480)
+    const bool quadlike = variant == PSGDK_GEOM_QUAD || variant == PSGDK_GEOM_QUAD4P;   // QUAD4P: two full steps on P itself
     const bool qep = variant == PSGDK_GEOM_QEP;
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
@@ -885,7 +892,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     launch_stage(P, P->g_upd_b, st);
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
-                                         P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off)));
+                                         P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off), P->p_mode() ? 1 : 0));
     // N-D tensors: Pg mode by mode, then every mode's Gram (dense -> term1 + its row stats; diagonal -> the sum vector)
     for (const GenDesc& g : P->gd) {
         const TensorDesc& D = P->td[g.tensor];
@@ -972,10 +979,10 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     {
         float* mu = (float*)(P->work + P->diag_mu_off);
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
-                                         P->work, mu, 0, lr_eff, betaL, variant == PSGDK_GEOM_QUAD ? 1 : 0));
+                                         P->work, mu, 0, lr_eff, betaL, quadlike ? 1 : 0));
         const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
-                                         P->state, P->work, mu, 1, lr_eff, betaL, variant == PSGDK_GEOM_QUAD ? 1 : 0));
+                                         P->state, P->work, mu, 1, lr_eff, betaL, quadlike ? 1 : 0));
     }
     if (!qep && (rc = run_balance(P, balance_mask, st))) return rc;
     HIPCHK(hipGetLastError());
@@ -994,6 +1001,10 @@ int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL
 int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                               uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
     return update_whiten_family(plan, PSGDK_GEOM_QUAD, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_quad4p(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                                uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_QUAD4P, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
 }
 int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                              uint64_t seed, uint64_t offset, void* stream) {
@@ -1129,7 +1140,7 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
                                          P->d_tiles_diag, P->state, P->work, 1, source == PSGDK_SRC_GRAD ? 1 : 0,
-                                         (float*)(P->work + P->hsumsq_off)));
+                                         (float*)(P->work + P->hsumsq_off), P->p_mode() ? 1 : 0));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }

@@ -313,7 +313,7 @@ def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=floa
                        damping=1e-9, force_balance_at=None, seed=0):
     """The QEQ / QUAD geometries (psgd.py:367-391, 455-483) behind the same seam."""
     fn = {"QEQ": psgd.update_precond_kron_whiten_qeq, "QUAD": psgd.update_precond_kron_whiten_quad,
-          "QEP": psgd.update_precond_kron_whiten_qep}[geom]
+          "QEP": psgd.update_precond_kron_whiten_qep, "QUAD4P": psgd.update_precond_kron_whiten_quad4p}[geom]
     out = {"shape": np.asarray(shape, dtype=np.int64), "T": np.asarray(T), "max_skew": np.asarray(max_skew),
            "max_size": np.asarray(max_size), "Scale": np.asarray(Scale), "lr": np.asarray(lr),
            "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
@@ -338,7 +338,10 @@ def gen_kron_geom_case(geom, name, shape, dtypes, T, max_skew=1.0, max_size=floa
                     out[f"{dn}_t{t}_spd{i}"] = npy(r.draws[k][1])
                     k += 1
             out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1]) if geom != "QEP" else np.asarray(0.5)   # QEP draws no gate
-            out[f"{dn}_t{t}_h"] = npy(psgd.precond_grad_kron(QL, exprs, G))
+            if geom == "QUAD4P":       # KronWhiten applies exprA(*Q, G) for the P-fitting geometries (psgd.py:573)
+                out[f"{dn}_t{t}_h"] = npy(exprs[0](*QL[0], G))
+            else:
+                out[f"{dn}_t{t}_h"] = npy(psgd.precond_grad_kron(QL, exprs, G))
             for i, (q, ell) in enumerate(zip(*QL)):
                 out[f"{dn}_t{t}_Q{i}"] = npy(q)
                 out[f"{dn}_t{t}_L{i}"] = npy(ell)

@@ -153,20 +153,23 @@ def test_kronwhiten_eq_optimises():
                 assert float(torch.tril(q, -1).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_"))
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_") +
+                         golden_names("kronquad4p_"))
 def test_qeq_quad_functional_seam_vs_golden(name):
     """dQ = "QEQ" (psgd.py:367-391) and "QUAD" (psgd.py:455-483) through the C ABI vs the reference's outputs; Q itself is
     compared (neither geometry has the Procrustes gauge step)."""
     import psgd_torch_amd as amd
-    geom = {"kronqeq": "QEQ", "kronquad": "QUAD", "kronqep": "QEP"}[name.split("_")[0]]
-    qeq = geom != "QUAD"
+    geom = {"kronqeq": "QEQ", "kronquad": "QUAD", "kronqep": "QEP", "kronquad4p": "QUAD4P"}[name.split("_")[0]]
+    qeq = geom not in ("QUAD", "QUAD4P")
+    p4 = geom == "QUAD4P"
     upd_orc = {"QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
-               "QEP": orc.update_precond_kron_whiten_qep}[geom]
+               "QEP": orc.update_precond_kron_whiten_qep, "QUAD4P": orc.update_precond_kron_whiten_quad4p}[geom]
 
     def upd_amd(QL, exprs, G, balance=None, **kw):
         if geom == "QEP":
             return amd.update_precond_kron_whiten_qep(QL, exprs, G, **kw)
-        fn = amd.update_precond_kron_whiten_qeq if geom == "QEQ" else amd.update_precond_kron_whiten_quad
+        fn = {"QEQ": amd.update_precond_kron_whiten_qeq, "QUAD": amd.update_precond_kron_whiten_quad,
+              "QUAD4P": amd.update_precond_kron_whiten_quad4p}[geom]
         return fn(QL, exprs, G, balance=balance, **kw)
     z = load(name)
     lr, betaL, damping = float(z["lr"]), float(z["betaL"]), float(z["damping"])
@@ -176,7 +179,8 @@ def test_qeq_quad_functional_seam_vs_golden(name):
             continue
         dt = DT[dn]
         QL, exprs = amd.init_kron(T(z["G0"], dt).to(DEV), dQ=geom, **kw)
-        QL64, kinds = orc.init_kron(T(z["G0"], torch.float64), **kw)
+        kw64 = dict(kw, Scale=kw["Scale"] ** 2) if p4 else kw          # psgd.py:186-187
+        QL64, kinds = orc.init_kron(T(z["G0"], torch.float64), **kw64)
         for t in range(int(z["T"])):
             Gd = T(z[f"G{t}"], dt)
             noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
@@ -186,7 +190,7 @@ def test_qeq_quad_functional_seam_vs_golden(name):
             n64 = orc.KronNoise(noise.g_noise.double(), [x.double() if x is not None else None for x in noise.spd],
                                 [None] * len(noise.spd), noise.balance_u)
             upd_orc(QL64, Gd.double(), n64, lr=lr, betaL=betaL, damping=damping)
-            h64 = orc.precond_grad_kron(QL64[0], Gd.double())
+            h64 = orc.precond_grad_kron_4p(QL64[0], Gd.double()) if p4 else orc.precond_grad_kron(QL64[0], Gd.double())
             checks = [("h", h, z[f"{dn}_t{t}_h"], h64)]
             for i in range(len(QL[0])):
                 checks.append((f"Q{i}", QL[0][i], z[f"{dn}_t{t}_Q{i}"], QL64[0][i]))
@@ -202,7 +206,7 @@ def test_qeq_quad_functional_seam_vs_golden(name):
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
 
-@pytest.mark.parametrize("dQ", ["QEQ", "QUAD", "QEP"])
+@pytest.mark.parametrize("dQ", ["QEQ", "QUAD", "QEP", "QUAD4P"])
 def test_kronwhiten_other_geometries_optimise(dQ):
     """KronWhiten(dQ=...) on an ill-conditioned least-squares problem: converges by orders of magnitude."""
     from psgd_torch_amd import KronWhiten

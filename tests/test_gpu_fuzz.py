@@ -1,5 +1,5 @@
 """Randomised differential test of the HIP path against the CPU oracle (fp32, explicit noise): random shapes (odd sizes,
-singleton dims, 0..4 dims), dense/diagonal decisions (max_skew, max_size), all five built geometries, a few steps each.
+singleton dims, 0..4 dims), dense/diagonal decisions (max_skew, max_size), all six built geometries, a few steps each.
 Catches layout / edge-tile / padding mistakes the fixed golden shapes may miss; the oracle is pinned to the reference by
 tests/test_oracle_golden.py."""
 import random
@@ -13,7 +13,7 @@ from oracle import psgd_oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-GEOMS = ["Q0.5EQ1.5", "EQ", "QEQ", "QUAD", "QEP"]
+GEOMS = ["Q0.5EQ1.5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P"]
 
 
 def _case(seed):
@@ -41,14 +41,14 @@ def test_random_case_matches_oracle(seed):
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
     upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
                "QEQ": amd.update_precond_kron_whiten_qeq, "QUAD": amd.update_precond_kron_whiten_quad,
-               "QEP": amd.update_precond_kron_whiten_qep}[geom]
+               "QEP": amd.update_precond_kron_whiten_qep, "QUAD4P": amd.update_precond_kron_whiten_quad4p}[geom]
     upd_orc = {"Q0.5EQ1.5": orc.update_precond_kron_whiten_q0p5eq1p5, "EQ": orc.update_precond_kron_whiten_eq,
                "QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
-               "QEP": orc.update_precond_kron_whiten_qep}[geom]
+               "QEP": orc.update_precond_kron_whiten_qep, "QUAD4P": orc.update_precond_kron_whiten_quad4p}[geom]
     gen = torch.Generator().manual_seed(1000 + seed)
     kw = dict(Scale=0.7, max_size=max_size, max_skew=max_skew)
     QL, exprs = amd.init_kron(torch.zeros(sq, device=DEV), dQ=geom, **kw)
-    QLo, kinds = orc.init_kron(torch.zeros(sq), **kw)
+    QLo, kinds = orc.init_kron(torch.zeros(sq), **(dict(kw, Scale=0.7 ** 2) if geom == "QUAD4P" else kw))   # psgd.py:186-187
     assert [q.dim() == 2 for q in QL[0]] == [k == "dense" for k in kinds], (shape, kinds)
     for t in range(3):
         G = 0.5 * torch.randn(sq, generator=gen)
@@ -62,7 +62,7 @@ def test_random_case_matches_oracle(seed):
         upd_amd(QL, exprs, G.to(DEV), **kwargs)
         upd_orc(QLo, G, nz, lr=0.2, betaL=0.9, damping=1e-6)
         h = amd.precond_grad_kron(QL, exprs, G.to(DEV))
-        ho = orc.precond_grad_kron(QLo[0], G)
+        ho = orc.precond_grad_kron_4p(QLo[0], G) if geom == "QUAD4P" else orc.precond_grad_kron(QLo[0], G)
         tag = (seed, shape, max_skew, max_size, geom, t)
         assert relerr(h, ho) <= 2e-4, tag + ("h", relerr(h, ho))
         for i in range(len(QL[0])):

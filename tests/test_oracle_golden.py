@@ -84,21 +84,23 @@ def test_kron_eq_update_and_apply(name):
                     assert float(torch.tril(q, -1).abs().max()) == 0.0        # Q stays upper triangular
 
 
-@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_"))
+@pytest.mark.parametrize("name", golden_names("kronqeq_") + golden_names("kronquad_") + golden_names("kronqep_") +
+                         golden_names("kronquad4p_"))
 def test_kron_qeq_quad_update_and_apply(name):
-    """The QEQ / QUAD / QEP geometries (psgd.py:367-391, 455-483, 339-364) against the reference's own outputs."""
+    """The QEQ / QUAD / QEP / QUAD4P geometries (psgd.py:367-391, 455-483, 339-364, 486-513) against the reference's outputs."""
     fn = {"kronqeq": orc.update_precond_kron_whiten_qeq, "kronquad": orc.update_precond_kron_whiten_quad,
-          "kronqep": orc.update_precond_kron_whiten_qep}[name.split("_")[0]]
+          "kronqep": orc.update_precond_kron_whiten_qep, "kronquad4p": orc.update_precond_kron_whiten_quad4p}[name.split("_")[0]]
+    p4 = name.startswith("kronquad4p_")
     z = load(name)
     for dn in kron_dtypes(z):
         dt = DT[dn]
-        QL, kinds = orc.init_kron(T(z["G0"], dt), Scale=float(z["Scale"]), max_size=float(z["max_size"]),
-                                  max_skew=float(z["max_skew"]))
+        QL, kinds = orc.init_kron(T(z["G0"], dt), Scale=float(z["Scale"]) ** (2 if p4 else 1), max_size=float(z["max_size"]),
+                                  max_skew=float(z["max_skew"]))         # psgd.py:186-187: Scale is squared when fitting P
         for t in range(int(z["T"])):
             G = T(z[f"G{t}"], dt)
             noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
             fn(QL, G, noise, lr=float(z["lr"]), betaL=float(z["betaL"]), damping=float(z["damping"]))
-            h = orc.precond_grad_kron(QL[0], G)
+            h = orc.precond_grad_kron_4p(QL[0], G) if p4 else orc.precond_grad_kron(QL[0], G)
             assert relerr(h, z[f"{dn}_t{t}_h"]) <= TOL[dn], (name, dn, t, "h")
             for i, (q, ell) in enumerate(zip(*QL)):
                 assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= TOL[dn], (name, dn, t, i, "Q")
