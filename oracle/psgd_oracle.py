@@ -161,6 +161,24 @@ def procrustes_step2(Q: Tensor, noise: Tensor, max_step_size: float = 1 / 8) -> 
     Q.add_(a * (RQ + 0.5 * a * RRQ))
 
 
+def procrustes_step3(Q: Tensor, noise: Tensor, max_step_size: float = 1 / 3) -> None:
+    """psgd.py:127-158, in place on Q (third-order expansion of the rotation; used by the PRO4P geometry)."""
+    R = Q.t() - Q
+    R = R / (norm_lower_bound_skh(R, noise) + torch.finfo(R.dtype).smallest_normal)
+    RQ = R @ Q
+    RRQ = R @ RQ
+    RRRQ = R @ RRQ
+    tr_RQ = RQ.diagonal().sum()
+    tr_RRQ = RRQ.diagonal().sum()
+    tr_RRRQ = RRRQ.diagonal().sum()
+    if tr_RQ > 0 and tr_RRRQ < 0:
+        if torch.finfo(tr_RQ.dtype).eps > 1e-6:
+            tr_RQ, tr_RRQ, tr_RRRQ = tr_RQ.to(torch.float32), tr_RRQ.to(torch.float32), tr_RRRQ.to(torch.float32)
+        a = (-tr_RRQ - torch.sqrt(tr_RRQ * tr_RRQ - 1.5 * tr_RQ * tr_RRRQ)) / (0.75 * tr_RRRQ)
+        a = torch.clamp(a, max=max_step_size)
+        Q.add_(a * (RQ + 0.5 * a * (RRQ + 0.25 * a * RRRQ)))
+
+
 def balance_kron_precond(Q: List[Tensor]) -> None:
     """psgd.py:266-275."""
     order = len(Q)
@@ -330,6 +348,42 @@ def update_precond_kron_whiten_quad4p(QL, G: Tensor, noise: KronNoise, lr: float
             q.copy_((p + p.t()) / 2)
     if noise.balance_u < 0.01:
         balance_kron_precond(Q)
+
+
+def update_precond_kron_whiten_pro4p(QL, G: Tensor, noise: KronNoise, pro_noise, lr: float = 0.1, betaL: float = 0.9,
+                                     damping: float = 1e-9) -> List[int]:
+    """psgd.py:422-452: fits P directly with dP = P^0.5 E P; after the gradient step up to 10 procrustes_step3 rotations
+    bring each dense factor back to (almost) Hermitian.  pro_noise[i] = list of the (32, d) draws of the successive
+    procrustes_step3 calls of dense factor i (at least as many as get used).  Returns the number of rotations per factor."""
+    Q, L = QL
+    total_numel = G.numel()
+    damp = damping + torch.finfo(G.dtype).eps * G.abs()
+    Pg = apply_q_kron(Q, G + damp * noise.g_noise.to(G.dtype))
+    used = []
+    for i, q in enumerate(Q):
+        dense = q.dim() >= 2
+        term1 = gram_mode(Pg, i, dense)
+        if not dense:
+            term2 = total_numel / q.numel()
+            ell = torch.max(term1) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.mul_(1 - lr / L[i] * (term1 - term2))
+            used.append(0)
+        else:
+            term2 = total_numel / q.shape[0]
+            ell = norm_lower_bound_spd(term1, noise.spd[i]) + term2
+            L[i].copy_(torch.max(betaL * L[i] + (1 - betaL) * ell, ell))
+            q.sub_(lr / L[i] * (term1 @ q - term2 * q))
+            n = 0
+            for k in range(10):
+                procrustes_step3(q, pro_noise[i][k].to(q.dtype))
+                n += 1
+                if (q.t() - q).abs().amax() < 0.001 * q.abs().amax():
+                    break
+            used.append(n)
+    if noise.balance_u < 0.01:
+        balance_kron_precond(Q)
+    return used
 
 
 def precond_grad_kron_4p(Q: List[Tensor], G: Tensor) -> Tensor:

@@ -360,6 +360,74 @@ def gen_kron_geoms():
         gen_kron_geom_case(geom, "t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=b + 6)
 
 
+def gen_kron_pro4p_case(name, shape, dtypes, T, max_skew=1.0, max_size=float("inf"), Scale=0.8, lr=0.3, betaL=0.9,
+                        damping=1e-9, force_balance_at=None, seed=0):
+    """PRO4P (psgd.py:422-452): fits P directly; a variable number (1..10) of procrustes_step3 calls per dense factor, each
+    with its own (32, d) draw.  Stored per step and dense factor i: spd{i}, npro{i}, pro{i}_{k}."""
+    out = {"shape": np.asarray(shape, dtype=np.int64), "T": np.asarray(T), "max_skew": np.asarray(max_skew),
+           "max_size": np.asarray(max_size), "Scale": np.asarray(Scale), "lr": np.asarray(lr),
+           "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
+    G32 = structured_grads(shape, T, seed + 1)
+    for t in range(T):
+        out[f"G{t}"] = npy(G32[t])
+    events = []
+    o_spd, o_pro = psgd.norm_lower_bound_spd, psgd.procrustes_step3
+
+    def spd(*a, **k):
+        events.append("spd")
+        return o_spd(*a, **k)
+
+    def pro(*a, **k):
+        events.append("pro")
+        return o_pro(*a, **k)
+    psgd.norm_lower_bound_spd, psgd.procrustes_step3 = spd, pro
+    try:
+        for dn in dtypes:
+            dt = DT[dn]
+            QL, exprs = psgd.init_kron(G32[0].to(dt), Scale=Scale, max_size=max_size, max_skew=max_skew, dQ="PRO4P")
+            torch.manual_seed(4000 + seed)
+            for t in range(T):
+                G = G32[t].to(dt)
+                del events[:]
+                force = [0.001 if force_balance_at == t else 0.5]
+                with Recorder(force_rand=force) as r:
+                    psgd.update_precond_kron_whiten_pro4p(QL, exprs, G, lr=lr, betaL=betaL, damping=damping)
+                counts = []
+                for e in events:
+                    if e == "spd":
+                        counts.append(0)
+                    else:
+                        counts[-1] += 1
+                out[f"{dn}_t{t}_gnoise"] = npy(r.draws[0][1])
+                k, c = 1, 0
+                for i, q in enumerate(QL[0]):
+                    if q.dim() == 2:
+                        out[f"{dn}_t{t}_spd{i}"] = npy(r.draws[k][1]); k += 1
+                        out[f"{dn}_t{t}_npro{i}"] = np.asarray(counts[c])
+                        for j in range(counts[c]):
+                            out[f"{dn}_t{t}_pro{i}_{j}"] = npy(r.draws[k][1]); k += 1
+                        c += 1
+                out[f"{dn}_t{t}_balance_u"] = npy(r.draws[k][1])
+                assert k + 1 == len(r.draws), (k, len(r.draws))
+                out[f"{dn}_t{t}_h"] = npy(exprs[0](*QL[0], G))
+                for i, (q, ell) in enumerate(zip(*QL)):
+                    out[f"{dn}_t{t}_Q{i}"] = npy(q)
+                    out[f"{dn}_t{t}_L{i}"] = npy(ell)
+    finally:
+        psgd.norm_lower_bound_spd, psgd.procrustes_step3 = o_spd, o_pro
+    save("kronpro4p_" + name, out)
+
+
+def gen_kron_pro4p():
+    all3 = ("fp64", "fp32", "bf16")
+    gen_kron_pro4p_case("vec33", (33,), all3, T=4, seed=131)
+    gen_kron_pro4p_case("m48x32", (48, 32), all3, T=6, seed=132)
+    gen_kron_pro4p_case("m32x48", (32, 48), all3, T=5, seed=133)
+    gen_kron_pro4p_case("m64x64", (64, 64), all3, T=4, seed=134, force_balance_at=2, lr=0.6)
+    gen_kron_pro4p_case("m150x200", (150, 200), ("fp32", "bf16"), T=2, seed=135)
+    gen_kron_pro4p_case("t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=136, lr=0.6)
+
+
 def gen_kron_eq():
     all3 = ("fp64", "fp32", "bf16")
     gen_kron_eq_case("scalar", (), all3, T=4, seed=51)
@@ -525,5 +593,6 @@ if __name__ == "__main__":
     gen_kron()
     gen_kron_eq()
     gen_kron_geoms()
+    gen_kron_pro4p()
     gen_kwns4()
     gen_lra()

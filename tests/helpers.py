@@ -49,3 +49,12 @@ def P_of(Q):
         q = torch.as_tensor(q).detach().cpu().to(torch.float64)
         out.append(q.t() @ q if q.dim() == 2 else q * q)
     return out
+
+
+def pro_noise_from_golden(z, dn, t, nfac, dtype):
+    """PRO4P goldens: per dense factor the draws of its successive procrustes_step3 calls (psgd.py:447-450)."""
+    out = []
+    for i in range(nfac):
+        key = f"{dn}_t{t}_npro{i}"
+        out.append([T(z[f"{dn}_t{t}_pro{i}_{k}"], dtype) for k in range(int(z[key]))] if key in z.files else None)
+    return out

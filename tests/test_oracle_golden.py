@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import DT, P_of, T, golden_names, kron_dtypes, kron_noise_from_golden, load, relerr
+from helpers import DT, P_of, T, golden_names, kron_dtypes, kron_noise_from_golden, load, pro_noise_from_golden, relerr
 from oracle import psgd_oracle as orc
 
 TOL = {"fp64": 1e-10, "fp32": 5e-6, "bf16": 4e-2}
@@ -105,6 +105,34 @@ def test_kron_qeq_quad_update_and_apply(name):
             for i, (q, ell) in enumerate(zip(*QL)):
                 assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= TOL[dn], (name, dn, t, i, "Q")
                 assert relerr(ell, z[f"{dn}_t{t}_L{i}"]) <= TOL[dn], (name, dn, t, i, "L")
+
+
+@pytest.mark.parametrize("name", golden_names("kronpro4p_"))
+def test_kron_pro4p_update_and_apply(name):
+    """PRO4P (psgd.py:422-452, procrustes_step3 psgd.py:127-158) against the reference's outputs, including the number of
+    rotations each dense factor took before its Hermitian-enough break.  fp32 tolerance 1e-3: fitting P directly amplifies
+    rounding differences (the reference's own warning, psgd.py:425-426; observed 1.7e-4 between two contraction orders)."""
+    tol = {"fp64": 1e-10, "fp32": 1e-3, "bf16": 4e-2}
+    z = load(name)
+    for dn in kron_dtypes(z):
+        dt = DT[dn]
+        QL, kinds = orc.init_kron(T(z["G0"], dt), Scale=float(z["Scale"]) ** 2, max_size=float(z["max_size"]),
+                                  max_skew=float(z["max_skew"]))
+        for t in range(int(z["T"])):
+            G = T(z[f"G{t}"], dt)
+            noise = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            pro = pro_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            padded = [None if p is None else p + [torch.zeros_like(p[0])] * (10 - len(p)) for p in pro]
+            used = orc.update_precond_kron_whiten_pro4p(QL, G, noise, padded, lr=float(z["lr"]), betaL=float(z["betaL"]),
+                                                        damping=float(z["damping"]))
+            for i, p in enumerate(pro):
+                if p is not None:
+                    assert used[i] == len(p), (name, dn, t, i, used[i], len(p))
+            h = orc.precond_grad_kron_4p(QL[0], G)
+            assert relerr(h, z[f"{dn}_t{t}_h"]) <= tol[dn], (name, dn, t, "h")
+            for i, (q, ell) in enumerate(zip(*QL)):
+                assert relerr(q, z[f"{dn}_t{t}_Q{i}"]) <= tol[dn], (name, dn, t, i, "Q")
+                assert relerr(ell, z[f"{dn}_t{t}_L{i}"]) <= tol[dn], (name, dn, t, i, "L")
 
 
 def _kw_from_golden(z):
