@@ -36,7 +36,7 @@ extern "C" {
 enum {
     PSGDK_OK = 0,
     PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
-    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (e.g. tensors with > 2 non-singleton dims) */
+    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (tensors with > 8 dims, LRA rank > 16) */
     PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
     PSGDK_ERR_STATE = 4        /* call order violated (e.g. arenas not bound) */
 };
@@ -72,7 +72,8 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
  * (upper-triangular Q, psgd.py:278-336; needs extra work buffers), PSGDK_GEOM_QEQ (psgd.py:367-391), PSGDK_GEOM_QUAD (symmetric Q, psgd.py:455-483), PSGDK_GEOM_QEP
  * (psgd.py:339-364), PSGDK_GEOM_QUAD4P (psgd.py:486-513: the factors ARE P; psgdk_precond_grad then applies every
  * factor once, as KronWhiten does for this choice, psgd.py:573; init scale is squared by the caller like psgd.py:186-187).
- * PRO4P is not built.  Each update entry point below requires the plan to
+ * PSGDK_GEOM_PRO4P (psgd.py:422-452): fits P with dP = P^0.5 E P; after the gradient step every dense factor takes up to
+ * ten procrustes_step3 rotations (psgd.py:127-158) and stops, per factor and on the device, once it is Hermitian to 1e-3.  Each update entry point below requires the plan to
  * carry its geometry (else PSGDK_ERR_STATE). */
 #define PSGDK_GEOM_Q0P5EQ1P5 0
 #define PSGDK_GEOM_EQ 1
@@ -80,6 +81,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids);
 #define PSGDK_GEOM_QUAD 3
 #define PSGDK_GEOM_QEP 4
 #define PSGDK_GEOM_QUAD4P 5
+#define PSGDK_GEOM_PRO4P 6
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry);
 
 /* arena sizes in bytes; caller allocates both zero-filled, 256-byte aligned, and binds them. */
@@ -154,6 +156,11 @@ int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float beta
 int psgdk_update_precond_quad4p(psgdk_plan* plan, int source, float lr, float betaL, float damping,
                                 const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                                 const uint8_t* balance_mask, void* stream);
+/* psgd.update_precond_kron_whiten_pro4p (psgd.py:422-452).  Explicit noise: skh_noise[slot] holds the draws of the successive
+ * procrustes_step3 calls of that factor back to back, 10 x 32 x d values (unused ones are never read). */
+int psgdk_update_precond_pro4p(psgdk_plan* plan, int source, float lr, float betaL, float damping,
+                               const psgdk_noise* noise, uint64_t seed, uint64_t offset,
+                               const uint8_t* balance_mask, void* stream);
 /* psgd.update_precond_kron_whiten_qep (psgd.py:339-364): balancing of every tensor FIRST and on every call (not optional,
  * psgd.py:346-347); per factor term1 = Gram_i(Q_i Pg), term2 = (numel/d) Q Q^T, ell = ||term1 + term2||_lb,
  * Q -= lr/L (term1 - term2) Q (diagonal: q *= 1 - lr/L (term1 - term2)).  No gate draw, hence no balance_mask. */

@@ -11,13 +11,14 @@ Everything computes through libpsgdk.so (hand-written HIP for gfx950, include/ps
 """
 from .kron import (init_kron, precond_grad_kron, update_precond_kron_whiten_eq,  # noqa: F401
                    update_precond_kron_whiten_q0p5eq1p5, update_precond_kron_whiten_qeq, update_precond_kron_whiten_quad,
-                   update_precond_kron_whiten_qep, update_precond_kron_whiten_quad4p)
+                   update_precond_kron_whiten_qep, update_precond_kron_whiten_quad4p,
+                   update_precond_kron_whiten_pro4p)
 from .kwns4 import KWNS4  # noqa: F401
 from .engine import KronEngine  # noqa: F401
 from .kron_whiten import KronWhiten  # noqa: F401
 from .lra import LRAWhiten, precond_grad_lra, update_precond_lra_whiten  # noqa: F401
 
 __all__ = ["KWNS4", "KronWhiten", "KronEngine", "init_kron", "update_precond_kron_whiten_q0p5eq1p5", "update_precond_kron_whiten_eq",
-           "update_precond_kron_whiten_qeq", "update_precond_kron_whiten_quad", "update_precond_kron_whiten_qep", "update_precond_kron_whiten_quad4p",
+           "update_precond_kron_whiten_qeq", "update_precond_kron_whiten_quad", "update_precond_kron_whiten_qep", "update_precond_kron_whiten_quad4p", "update_precond_kron_whiten_pro4p",
            "precond_grad_kron",
            "LRAWhiten", "update_precond_lra_whiten", "precond_grad_lra"]

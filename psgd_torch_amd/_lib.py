@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE = 0, 1, 2, 3, 4
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
-GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P = 0, 1, 2, 3, 4, 5
+GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
 
 
@@ -61,6 +61,8 @@ SIGNATURES = {
                                             C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.c_void_p]),
     "psgdk_update_precond_quad4p": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                               C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.c_void_p]),
+    "psgdk_update_precond_pro4p": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                             C.POINTER(Noise), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.c_void_p]),
     "psgdk_update_precond_qep": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                            C.POINTER(Noise), C.c_uint64, C.c_uint64, C.c_void_p]),
     "psgdk_update_precond_eq": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,

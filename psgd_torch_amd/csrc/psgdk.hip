@@ -23,6 +23,7 @@ struct Stage {                       // one grouped GEMM launch
     GemmTile* d_tiles = nullptr;
     unsigned n_tiles = 0;
     bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_big_kernel)
+    bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -68,10 +69,11 @@ struct psgdk_plan {
     // PSGDK_GEOM_EQ (psgd.py:278-336): A = (kron Q) Hvp in two products, Grams of A and B, Q -= mu triu(.) Q; the right
     // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
-    bool p_mode() const { return geometry == PSGDK_GEOM_QUAD4P; }      // the factors ARE P (fitted directly, psgd.py:486-513)
+    bool p_mode() const { return geometry == PSGDK_GEOM_QUAD4P || geometry == PSGDK_GEOM_PRO4P; }   // the factors ARE P (psgd.py:422-452, 486-513)
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
     Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
     Stage v_qep_u, v_qep_t1, v_qep_t2;               // PSGDK_GEOM_QEP: Q term1, (Q term1) Q^T, c Q Q^T
+    Stage v_pro_rq, v_pro_rrq, v_pro_rrrq;           // PSGDK_GEOM_PRO4P: the three products of procrustes_step3
     std::vector<int> e_gram_prob;                    // per dense factor: index into e_g1 / e_g2
     TrsmJob* d_trsm[2] = {nullptr, nullptr}; TrsmTile* d_trsm_tiles[2] = {nullptr, nullptr};
     unsigned n_trsm_tiles[2] = {0, 0};
@@ -84,7 +86,7 @@ struct psgdk_plan {
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
         for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
-        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2, &v_qep_u, &v_qep_t1, &v_qep_t2}) v.push_back(e);
+        for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2, &v_qep_u, &v_qep_t1, &v_qep_t2, &v_pro_rq, &v_pro_rrq, &v_pro_rrrq}) v.push_back(e);
         return v;
     }
 
@@ -126,7 +128,8 @@ template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
     if (s.big) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
-    else hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
+    else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
 }
 void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
@@ -393,7 +396,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 }
 
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
-    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_QUAD4P) return PSGDK_ERR_INVALID;
+    if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_PRO4P) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
     plan->geometry = geometry;
     layout_arenas(plan);
@@ -610,6 +613,26 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 P->v_quad2.probs.push_back(g);
             }
         }
+    if (P->geometry == PSGDK_GEOM_PRO4P) {
+        for (Stage* e : {&P->v_pro_rq, &P->v_pro_rrq, &P->v_pro_rrrq, &P->g_nlb[1][0], &P->g_nlb[1][1], &P->g_nlb[1][2], &P->g_nlb[1][3]}) e->ext = true;
+        for (size_t f = 0; f < P->dn.size(); ++f) {
+            // procrustes_step3 (psgd.py:127-158) on Q' (qn / qtn): RQ = s R Q', RRQ = s R RQ, then Q' += a (RQ + a/2 (RRQ + a/4 s R RRQ))
+            // with tr(RRQ) = -s <R, RQ> and tr(RRRQ) = -s <R, RRQ> from the epilogues of the first two products (R antisymmetric)
+            const DenseDesc& F = P->dn[f];
+            float* sc = (float*)(W + F.sc_off);
+            for (int p_ = 0; p_ < 4; ++p_) P->g_nlb[1][p_].probs[f].skip = sc + DS_DONE;
+            GemmProblem g{};
+            g.A = W + F.r_off; g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = g.ldq = g.lddot = F.dp; g.alpha = 1.f;
+            g.alpha_dev = sc + DS_S; g.skip = sc + DS_DONE; g.dot_with = W + F.r_off;
+            GemmProblem a = g; a.B = W + F.qtn_off; a.C = W + F.rq_off; a.Ct = W + F.rqt_off; a.trace = sc + DS_TR1; a.dot_out = sc + DS_TR2;
+            P->v_pro_rq.probs.push_back(a);
+            GemmProblem b = g; b.B = W + F.rqt_off; b.C = W + F.p_off; b.Ct = W + F.t1_off; b.dot_out = sc + DS_TR3;      // RRQ, RRQ^T
+            P->v_pro_rrq.probs.push_back(b);
+            GemmProblem c = g; c.dot_with = nullptr; c.B = W + F.t1_off; c.C = W + F.qn_off; c.Ct = W + F.qtn_off; c.flags = GF_PROCR3;
+            c.X1 = W + F.qn_off; c.X2 = W + F.rq_off; c.X3 = W + F.p_off; c.tr1_dev = sc + DS_TR1; c.tr2_dev = sc + DS_TR2; c.tr3_dev = sc + DS_TR3;
+            P->v_pro_rrrq.probs.push_back(c);
+        }
+    }
     if (P->geometry == PSGDK_GEOM_QEP)
         for (size_t f = 0; f < P->dn.size(); ++f) {
             // term1 = Gram_i(Q_i Pg) = Q T1 Q^T with T1 the mode Gram of Pg; term2 = c Q Q^T (psgd.py:353-361)
@@ -846,7 +869,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     if (!plan->state || plan->geometry != variant) return PSGDK_ERR_STATE;
     if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
     if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
-    const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5;
+    const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5 || variant == PSGDK_GEOM_PRO4P;
     if (noise && (!noise->g_noise || (!plan->dn.empty() && (!noise->spd_noise || (need_skh && !noise->skh_noise))))) return PSGDK_ERR_INVALID;
     const float lr_eff = variant == PSGDK_GEOM_QUAD ? 0.5f * lr : lr;       // QUAD takes two half steps (psgd.py:473,479-480)
     const bool quadlike = variant == PSGDK_GEOM_QUAD || variant == PSGDK_GEOM_QUAD4P;   // QUAD4P: two full steps on P itself
@@ -956,6 +979,22 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1));
             launch_stage(P, P->g_rq, st);
             launch_stage(P, P->g_rrq, st);
+        } else if (variant == PSGDK_GEOM_PRO4P) {
+            // P' = P - mu (term1 P - c P), then up to 10 procrustes_step3 rotations per factor; each factor stops once it is
+            // Hermitian to 1e-3 (device flag, psgd.py:447-450); finally into the state
+            launch_stage(P, P->g_qupd, st);
+            for (int k = 0; k < 10; ++k) {
+                DISPATCH_T(P, hipLaunchKernelGGL(pro_reset_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->work));
+                DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1));
+                if (k > 0) DISPATCH_T(P, hipLaunchKernelGGL(pro_decide_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->work));
+                DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset, k));
+                for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
+                DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1, 1));
+                launch_stage(P, P->v_pro_rq, st);
+                launch_stage(P, P->v_pro_rrq, st);
+                launch_stage(P, P->v_pro_rrrq, st);
+            }
+            DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
         } else if (variant == PSGDK_GEOM_QEQ) {
             // Q' = Q - mu (Q term1 - c Q) (psgd.py:388), then into the state
             launch_stage(P, P->v_qeq, st);
@@ -1005,6 +1044,10 @@ int psgdk_update_precond_quad(psgdk_plan* plan, int source, float lr, float beta
 int psgdk_update_precond_quad4p(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                                 uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
     return update_whiten_family(plan, PSGDK_GEOM_QUAD4P, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_pro4p(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
+                               uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_PRO4P, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
 }
 int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                              uint64_t seed, uint64_t offset, void* stream) {

@@ -71,9 +71,9 @@ class KronEngine:
         tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices).
         geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5", "EQ" (upper-triangular Q), "QEQ", "QUAD", "QEP"."""
         codes = {"Q0.5EQ1.5": L.GEOM_Q0P5EQ1P5, "Q0p5EQ1p5": L.GEOM_Q0P5EQ1P5, "EQ": L.GEOM_EQ, "QEQ": L.GEOM_QEQ,
-                 "QUAD": L.GEOM_QUAD, "QEP": L.GEOM_QEP, "QUAD4P": L.GEOM_QUAD4P}
+                 "QUAD": L.GEOM_QUAD, "QEP": L.GEOM_QEP, "QUAD4P": L.GEOM_QUAD4P, "PRO4P": L.GEOM_PRO4P}
         if geometry not in codes:
-            raise NotImplementedError(f"dQ={geometry!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD, QEP, QUAD4P")
+            raise NotImplementedError(f"dQ={geometry!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD, QEP, QUAD4P, PRO4P")
         self.geometry = codes[geometry]
         self.lib = L.lib()
         self.device = torch.device(device)
@@ -237,7 +237,7 @@ class KronEngine:
             return
         fn = {L.GEOM_Q0P5EQ1P5: self.lib.psgdk_update_precond_q0p5eq1p5, L.GEOM_EQ: self.lib.psgdk_update_precond_eq,
               L.GEOM_QEQ: self.lib.psgdk_update_precond_qeq, L.GEOM_QUAD: self.lib.psgdk_update_precond_quad,
-              L.GEOM_QUAD4P: self.lib.psgdk_update_precond_quad4p}[self.geometry]
+              L.GEOM_QUAD4P: self.lib.psgdk_update_precond_quad4p, L.GEOM_PRO4P: self.lib.psgdk_update_precond_pro4p}[self.geometry]
         L.check(fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed), int(offset), bm,
                    self._stream()), "update_precond")
         self._keep_noise = keep

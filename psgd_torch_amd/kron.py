@@ -18,18 +18,18 @@ import torch
 from . import _lib as L
 from .engine import KronEngine
 
-_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P"}
+_SUPPORTED_DQ = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"}
 
 
 def init_kron(t: torch.Tensor, Scale=1.0, max_size=float("inf"), max_skew=1.0, dQ="Q0.5EQ1.5"):
     """psgd.py:161-263.  Returns [[Q, L], exprs]; t must live on a ROCm device in bf16 or fp32."""
     if dQ not in _SUPPORTED_DQ:
-        raise NotImplementedError(f"dQ={dQ!r}: built geometries are Q0.5EQ1.5 (the one KWNS4 uses), EQ, QEQ, QUAD, QEP and QUAD4P")
+        raise NotImplementedError(f"dQ={dQ!r}: built geometries are Q0.5EQ1.5 (the one KWNS4 uses), EQ, QEQ, QUAD, QEP, QUAD4P and PRO4P")
     if t.dim() > 26:
         raise ValueError(f"Got tensor with dim {t.dim()}; einsum runs out of letters; replace 26 with larger numbers.")
     if torch.is_complex(t):
         raise NotImplementedError("real tensors only (as wrapped_as_torch_optimizer_for_ddp.KWNS4)")
-    if dQ == "QUAD4P":           # the factors are P itself: the scale is squared (psgd.py:186-187)
+    if dQ in ("QUAD4P", "PRO4P"):           # the factors are P itself: the scale is squared (psgd.py:186-187)
         Scale = Scale ** 2
     eng = KronEngine([tuple(t.shape)], t.device, precond_dtype=t.dtype, max_size=max_size, max_skew=max_skew,
                      use_momentum=False, init_scale=float(Scale), geometry=dQ)
@@ -98,6 +98,13 @@ def update_precond_kron_whiten_quad4p(QL, exprs, G, lr=0.1, betaL=0.9, damping=1
     """psgd.py:486-513 (fits P directly; QL/exprs from init_kron(..., dQ="QUAD4P")), in place on QL.  precond_grad_kron on
     such QL/exprs applies every factor once (what KronWhiten does for this dQ, psgd.py:573)."""
     _update_family(L.GEOM_QUAD4P, "QUAD4P", QL, exprs, G, lr, betaL, damping, noise, balance)
+
+
+def update_precond_kron_whiten_pro4p(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9, *, noise=None, balance=None):
+    """psgd.py:422-452 (fits P directly, dP = P^0.5 E P, with up to ten procrustes_step3 rotations per dense factor;
+    QL/exprs from init_kron(..., dQ="PRO4P")), in place on QL.  Explicit noise: the skh entry of a factor holds the draws
+    of its successive rotations stacked, shape (10 * 32, d)."""
+    _update_family(L.GEOM_PRO4P, "PRO4P", QL, exprs, G, lr, betaL, damping, noise, balance)
 
 
 def update_precond_kron_whiten_qep(QL, exprs, G, lr=0.1, betaL=0.9, damping=1e-9, *, noise=None):

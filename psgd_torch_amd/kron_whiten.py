@@ -32,8 +32,8 @@ class KronWhiten:
         self.preconditioner_update_probability = preconditioner_update_probability
         self.update_preconditioner_first = update_preconditioner_first
         # protected members
-        if dQ not in {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P"}:
-            raise NotImplementedError(f"dQ={dQ!r}: built geometries are Q0.5EQ1.5, EQ, QEQ, QUAD, QEP and QUAD4P")
+        if dQ not in {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"}:
+            raise NotImplementedError(f"dQ={dQ!r}: all seven geometries of the reference are built")
         self._dQ = dQ
         self._preconditioner_max_size = preconditioner_max_size
         self._preconditioner_max_skew = preconditioner_max_skew
@@ -58,7 +58,7 @@ class KronWhiten:
         p0 = self._params_with_grad[0]
         self._engine = KronEngine([tuple(g.shape) for g in grads], p0.device, precond_dtype=grads[0].dtype,
                                   max_size=self._preconditioner_max_size, max_skew=self._preconditioner_max_skew,
-                                  use_momentum=True, init_scale=float(scale) ** (2 if self._dQ == "QUAD4P" else 1),
+                                  use_momentum=True, init_scale=float(scale) ** (2 if self._dQ in ("QUAD4P", "PRO4P") else 1),
                                   geometry=self._dQ)
         self._QLs = [self._engine.QL(k) for k in range(len(grads))]
 

@@ -6,7 +6,7 @@ has no orthogonal gauge freedom: the reference's Q is reproduced, not only P = Q
 import pytest
 import torch
 
-from helpers import DT, P_of, T, golden_names, kron_dtypes, kron_noise_from_golden, load, relerr
+from helpers import DT, P_of, T, golden_names, kron_dtypes, kron_noise_from_golden, load, pro_noise_from_golden, relerr
 from oracle import psgd_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -206,7 +206,7 @@ def test_qeq_quad_functional_seam_vs_golden(name):
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
 
-@pytest.mark.parametrize("dQ", ["QEQ", "QUAD", "QEP", "QUAD4P"])
+@pytest.mark.parametrize("dQ", ["QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"])
 def test_kronwhiten_other_geometries_optimise(dQ):
     """KronWhiten(dQ=...) on an ill-conditioned least-squares problem: converges by orders of magnitude."""
     from psgd_torch_amd import KronWhiten
@@ -226,3 +226,49 @@ def test_kronwhiten_other_geometries_optimise(dQ):
         opt.step(loss)
     l1 = float(loss().detach())
     assert l1 < 1e-3 * l0, (dQ, l0, l1)
+
+
+@pytest.mark.parametrize("name", golden_names("kronpro4p_"))
+def test_pro4p_functional_seam_vs_golden(name):
+    """dQ = "PRO4P" (psgd.py:422-452 with procrustes_step3, psgd.py:127-158) through the C ABI.  The rotation count per
+    factor is decided on the device; the golden's draws are stacked (unused ones zero).  fp32 bound 1e-3 (fitting P directly
+    amplifies rounding -- the oracle itself is 1.7e-4 from the reference); bf16 as elsewhere."""
+    import psgd_torch_amd as amd
+    z = load(name)
+    lr, betaL, damping = float(z["lr"]), float(z["betaL"]), float(z["damping"])
+    kw = dict(Scale=float(z["Scale"]), max_size=float(z["max_size"]), max_skew=float(z["max_skew"]))
+    for dn in kron_dtypes(z):
+        if dn == "fp64":
+            continue
+        dt = DT[dn]
+        QL, exprs = amd.init_kron(T(z["G0"], dt).to(DEV), dQ="PRO4P", **kw)
+        QL64, kinds = orc.init_kron(T(z["G0"], torch.float64), **dict(kw, Scale=kw["Scale"] ** 2))
+        for t in range(int(z["T"])):
+            Gd = T(z[f"G{t}"], dt)
+            nz = kron_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            pro = pro_noise_from_golden(z, dn, t, len(QL[0]), dt)
+            stacked = {}
+            for i, p in enumerate(pro):
+                if p is not None:
+                    full = p + [torch.zeros_like(p[0])] * (10 - len(p))
+                    stacked[(0, i)] = torch.cat(full, dim=0).to(DEV)
+            dev_noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd) if x is not None}, stacked)
+            amd.update_precond_kron_whiten_pro4p(QL, exprs, Gd.to(DEV), lr=lr, betaL=betaL, damping=damping, noise=dev_noise,
+                                                 balance=nz.balance_u < 0.01)
+            h = amd.precond_grad_kron(QL, exprs, Gd.to(DEV))
+            n64 = orc.KronNoise(nz.g_noise.double(), [x.double() if x is not None else None for x in nz.spd],
+                                [None] * len(nz.spd), nz.balance_u)
+            pro64 = [None if p is None else [x.double() for x in p] + [torch.zeros_like(p[0]).double()] * (10 - len(p)) for p in pro]
+            orc.update_precond_kron_whiten_pro4p(QL64, Gd.double(), n64, pro64, lr=lr, betaL=betaL, damping=damping)
+            h64 = orc.precond_grad_kron_4p(QL64[0], Gd.double())
+            checks = [("h", h, z[f"{dn}_t{t}_h"], h64)]
+            for i in range(len(QL[0])):
+                checks.append((f"Q{i}", QL[0][i], z[f"{dn}_t{t}_Q{i}"], QL64[0][i]))
+                checks.append((f"L{i}", QL[1][i], z[f"{dn}_t{t}_L{i}"], QL64[1][i]))
+            for what, got, gold, truth in checks:
+                if dn == "fp32":
+                    assert relerr(got, gold) <= 1e-3, (name, dn, t, what, relerr(got, gold))
+                else:
+                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
+                    assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)

@@ -1,5 +1,5 @@
 """Randomised differential test of the HIP path against the CPU oracle (fp32, explicit noise): random shapes (odd sizes,
-singleton dims, 0..4 dims), dense/diagonal decisions (max_skew, max_size), all six built geometries, a few steps each.
+singleton dims, 0..4 dims), dense/diagonal decisions (max_skew, max_size), all seven geometries, a few steps each.
 Catches layout / edge-tile / padding mistakes the fixed golden shapes may miss; the oracle is pinned to the reference by
 tests/test_oracle_golden.py."""
 import random
@@ -13,7 +13,7 @@ from oracle import psgd_oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-GEOMS = ["Q0.5EQ1.5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P"]
+GEOMS = ["Q0.5EQ1.5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"]
 
 
 def _case(seed):
@@ -41,36 +41,47 @@ def test_random_case_matches_oracle(seed):
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
     upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
                "QEQ": amd.update_precond_kron_whiten_qeq, "QUAD": amd.update_precond_kron_whiten_quad,
-               "QEP": amd.update_precond_kron_whiten_qep, "QUAD4P": amd.update_precond_kron_whiten_quad4p}[geom]
+               "QEP": amd.update_precond_kron_whiten_qep, "QUAD4P": amd.update_precond_kron_whiten_quad4p,
+               "PRO4P": amd.update_precond_kron_whiten_pro4p}[geom]
     upd_orc = {"Q0.5EQ1.5": orc.update_precond_kron_whiten_q0p5eq1p5, "EQ": orc.update_precond_kron_whiten_eq,
                "QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
-               "QEP": orc.update_precond_kron_whiten_qep, "QUAD4P": orc.update_precond_kron_whiten_quad4p}[geom]
+               "QEP": orc.update_precond_kron_whiten_qep, "QUAD4P": orc.update_precond_kron_whiten_quad4p,
+               "PRO4P": orc.update_precond_kron_whiten_pro4p}[geom]
+    p4 = geom in ("QUAD4P", "PRO4P")
+    tol = 2e-3 if geom == "PRO4P" else 2e-4        # fitting P with repeated rotations amplifies fp32 rounding (psgd.py:425-426)
     gen = torch.Generator().manual_seed(1000 + seed)
     kw = dict(Scale=0.7, max_size=max_size, max_skew=max_skew)
     QL, exprs = amd.init_kron(torch.zeros(sq, device=DEV), dQ=geom, **kw)
-    QLo, kinds = orc.init_kron(torch.zeros(sq), **(dict(kw, Scale=0.7 ** 2) if geom == "QUAD4P" else kw))   # psgd.py:186-187
+    QLo, kinds = orc.init_kron(torch.zeros(sq), **(dict(kw, Scale=0.7 ** 2) if p4 else kw))   # psgd.py:186-187
     assert [q.dim() == 2 for q in QL[0]] == [k == "dense" for k in kinds], (shape, kinds)
     for t in range(3):
         G = 0.5 * torch.randn(sq, generator=gen)
         nz = orc.KronNoise.draw(G, kinds, gen)
         nz.balance_u = 0.0 if t == 1 else 1.0                  # exercise the balancing branch once
-        dev_noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd) if x is not None},
-                     {(0, i): x.to(DEV) for i, x in enumerate(nz.skh) if x is not None})
+        skh = {(0, i): x.to(DEV) for i, x in enumerate(nz.skh) if x is not None}
+        pro = None
+        if geom == "PRO4P":       # ten draws per dense factor for the successive procrustes_step3 calls, stacked for the ABI
+            pro = [None if x is None else [torch.randn(x.shape, generator=gen) for _ in range(10)] for x in nz.skh]
+            skh = {(0, i): torch.cat(p, dim=0).to(DEV) for i, p in enumerate(pro) if p is not None}
+        dev_noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd) if x is not None}, skh)
         kwargs = dict(lr=0.2, betaL=0.9, damping=1e-6, noise=dev_noise)
         if geom != "QEP":
             kwargs["balance"] = nz.balance_u < 0.01
         upd_amd(QL, exprs, G.to(DEV), **kwargs)
-        upd_orc(QLo, G, nz, lr=0.2, betaL=0.9, damping=1e-6)
+        if geom == "PRO4P":
+            upd_orc(QLo, G, nz, pro, lr=0.2, betaL=0.9, damping=1e-6)
+        else:
+            upd_orc(QLo, G, nz, lr=0.2, betaL=0.9, damping=1e-6)
         h = amd.precond_grad_kron(QL, exprs, G.to(DEV))
-        ho = orc.precond_grad_kron_4p(QLo[0], G) if geom == "QUAD4P" else orc.precond_grad_kron(QLo[0], G)
+        ho = orc.precond_grad_kron_4p(QLo[0], G) if p4 else orc.precond_grad_kron(QLo[0], G)
         tag = (seed, shape, max_skew, max_size, geom, t)
-        assert relerr(h, ho) <= 2e-4, tag + ("h", relerr(h, ho))
+        assert relerr(h, ho) <= tol, tag + ("h", relerr(h, ho))
         for i in range(len(QL[0])):
             if geom == "Q0.5EQ1.5":                            # Q is gauge dependent there (Procrustes on rounding noise)
-                assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= 2e-4, tag + (i, "P")
+                assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= tol, tag + (i, "P")
             else:
-                assert relerr(QL[0][i], QLo[0][i]) <= 2e-4, tag + (i, "Q")
-            assert relerr(QL[1][i], QLo[1][i]) <= 2e-4, tag + (i, "L")
+                assert relerr(QL[0][i], QLo[0][i]) <= tol, tag + (i, "Q")
+            assert relerr(QL[1][i], QLo[1][i]) <= tol, tag + (i, "L")
 
 
 M_CASES = int(os.environ.get("PSGDK_FUZZ_KWNS4", "12"))

@@ -11,8 +11,8 @@ import sys
 
 def key_of(name):
     name = re.sub(r"\s*\[clone .*\]$", "", name)
-    m = re.match(r"_Z\d+([A-Za-z0-9_]+?)I([tf])E", name)
-    d = re.match(r"void (\w+)<(unsigned short|float)>", name)
+    m = re.match(r"_Z\d+([A-Za-z0-9_]+?)I([tf])(?:Lb\d+E)?E", name)
+    d = re.match(r"void (\w+)<(unsigned short|float)(?:, \w+)?>", name)
     if m:
         return m.group(1) + "I" + m.group(2)
     if d:
