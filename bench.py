@@ -39,8 +39,10 @@ def gpt2_shapes(n_layer=12, n_embd=768, vocab=50304, block=1024):
     return s
 
 
-def flop_model(shapes, max_skew=1.0):
-    """SURVEY 8d.  Returns (step FLOPs, FLOPs that run in the grouped GEMM kernel)."""
+def flop_model(shapes, max_skew=1.0, nlb_in_gemm=True):
+    """SURVEY 8d.  Returns (step FLOPs, FLOPs that run in the grouped GEMM kernel).  The subspace iterations of the two norm
+    bounds (2 x 4 products of a 32 x d block: 512 d^2) are grouped-GEMM problems only on the multi-launch route; when the
+    cooperative kernel runs them (Engine.info()["nlb_coop"]) they are not part of the GEMM launches that are timed."""
     step = gemm = 0.0
     for shp in shapes:
         N = math.prod(shp)
@@ -49,7 +51,7 @@ def flop_model(shapes, max_skew=1.0):
                 continue
             ap = min(4.0 * N * d, 2.0 * d ** 3 + 2.0 * N * d)
             step += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + 512.0 * d ** 2
-            gemm += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + 512.0 * d ** 2    # the subspace iterations are GEMM problems too
+            gemm += 2 * ap + 2.0 * N * d + 6.0 * d ** 3 + (512.0 * d ** 2 if nlb_in_gemm else 0.0)
     return step, gemm
 
 
@@ -306,7 +308,8 @@ def main():
         apply_only_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     ms_per_step = dt / args.steps * 1e3
-    step_flops, gemm_flops = flop_model(shapes)
+    nlb_coop = bool(engines) and all(e.info()["nlb_coop"] for e in engines)
+    step_flops, gemm_flops = flop_model(shapes, nlb_in_gemm=not nlb_coop)
     run_cpu = args.config == "gpt2-small"
     out = {
         "metric": "psgd_kron_step_throughput",
@@ -332,7 +335,9 @@ def main():
                                                                    if mode == "sharded" else f"replicas x{world} (no exchange step)"),
                    "parallelism_probe_ms": ({k: v * 1e3 for k, v in timing.items()} if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-                   "apply_only_ms_per_step": apply_only_ms},
+                   "apply_only_ms_per_step": apply_only_ms,
+                   "norm_bound_route": ("cooperative launch" + (" (L2 exchange)" if engines[0].info()["nlb_same_xcd"] else " (device-scope exchange)"))
+                                       if nlb_coop else "grouped-GEMM products"},
     }
     if world == 1 and gemm_launches and prof_steps:
         launches_per_step = gemm_launches / prof_steps

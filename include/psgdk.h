@@ -224,6 +224,15 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
 /* replaces psgd.precond_grad_lra (psgd.py:1055-1063): out = Q^T Q g. */
 int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream);
 
+/* ---- introspection (bench.py / tests; no reference counterpart): how the plan runs.  NLB_COOP: the norm lower bounds
+ * (psgd.py:46-93) run as one cooperative launch per bound instead of start block + 4 grouped-GEMM products + scalars (set at
+ * psgdk_plan_bind); NLB_SAME_XCD: its workgroups exchange through their XCD's L2 (placement verified by a probe). */
+#define PSGDK_INFO_NLB_COOP 0
+#define PSGDK_INFO_NLB_SAME_XCD 1
+#define PSGDK_INFO_DENSE_FACTORS 2
+#define PSGDK_INFO_MAX_DENSE_DIM 3   /* padded to a multiple of 64 */
+int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
+
 /* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): when enabled, every gemm_nt launch is
  * bracketed by hipEvents on the launch stream; psgdk_profile_read synchronises those events and returns the summed
  * launch time (ms) and the launch count since the last reset. */

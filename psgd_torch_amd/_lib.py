@@ -79,6 +79,7 @@ SIGNATURES = {
     "psgdk_lra_update_whiten": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_float,
                                           C.c_float, C.c_float, C.c_void_p]),
     "psgdk_lra_precond_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psgdk_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "psgdk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "psgdk_flat_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -62,6 +62,10 @@ struct psgdk_plan {
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
     int* d_balance = nullptr; float* d_balnorm = nullptr;
     int max_dp = 0;
+    int nlb_same_xcd = 0;             // members of a factor verified to share an XCD: exchange through its L2
+    bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
+    NlbJob* d_nlb_jobs = nullptr; int* d_nlb_sync = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
+    bool nlb_unfused = false;        // PSGDK_NLB_FUSED=0 at plan creation: keep the multi-launch route (tests compare the two)
     bool p_valid = false;
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
@@ -97,7 +101,7 @@ struct psgdk_plan {
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
-        fr(d_uinv);
+        fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_sync);
     }
 };
 
@@ -286,6 +290,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->n_tensors = n_tensors; P->dtype = precond_dtype; P->use_momentum = use_momentum ? 1 : 0;
     P->esz = precond_dtype == PSGDK_BF16 ? 2 : 4;
     P->max_size = max_size; P->max_skew = max_skew;
+    { const char* e = getenv("PSGDK_NLB_FUSED"); P->nlb_unfused = e && e[0] == '0'; }
     size_t dpos = 0;
     // ---- structure (init_kron's dense/diag rule) ----
     for (int t = 0; t < n_tensors; ++t) {
@@ -454,6 +459,8 @@ int psgdk_plan_ema_view(const psgdk_plan* plan, int t, size_t* offset, int64_t* 
     return PSGDK_OK;
 }
 
+static int nlb_plan_coop(psgdk_plan* P);
+
 int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if (!plan || !state_arena || !work_arena) return PSGDK_ERR_INVALID;
     if (((uintptr_t)state_arena & 255) || ((uintptr_t)work_arena & 255)) return PSGDK_ERR_INVALID;
@@ -465,6 +472,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if ((rc = upload(&P->d_td, P->td))) return rc;
     if ((rc = upload(&P->d_dd, P->dd))) return rc;
     if ((rc = upload(&P->d_dn, P->dn))) return rc;
+    if ((rc = nlb_plan_coop(P))) return rc;
     if ((rc = upload(&P->d_gd, P->gd))) return rc;
     // ---- elementwise tile tables ----
     std::vector<EwTile> all, diag;
@@ -846,6 +854,88 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     return PSGDK_OK;
 }
 
+
+// norm_lower_bound_spd (chain 0: A = term1 -> L, mu) / _skh (chain 1: A = R -> s) of every dense factor (psgd.py:46-93).
+// One cooperative launch (nlb_coop_kernel: A read once, kept in registers by the workgroups of the factor) when the widest
+// factor fits its register budget (bf16: dp <= 768, fp32: dp <= 384) and all workgroups are resident at once; otherwise start
+// block, four grouped-GEMM products and the scalars as separate launches.  PSGDK_NLB_FUSED=0 at plan creation forces the
+// latter (the tests compare the two).
+// Does workgroup b of a launch run on the XCD of b % 8?  Probed once per process; xcc[x] = hardware XCC id of slot x.
+static int probe_xcc_map(int (&xcc)[8], bool* consistent) {
+    static int cached = -1, map[8];
+    if (cached < 0) {
+        int* d = nullptr; int h[64];
+        HIPCHK(hipMalloc((void**)&d, sizeof(h)));
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, nullptr, d);
+        HIPCHK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        cached = 1;
+        for (int b = 0; b < 64; ++b) if (h[b] != h[b % 8]) cached = 0;
+        for (int x = 0; x < 8; ++x) map[x] = h[x];
+    }
+    for (int x = 0; x < 8; ++x) xcc[x] = map[x];
+    *consistent = cached == 1;
+    return PSGDK_OK;
+}
+static int nlb_plan_coop(psgdk_plan* P) {
+    P->nlb_coop = false;
+    if (P->nlb_unfused || P->dn.empty()) return PSGDK_OK;
+    const int kstep = P->dtype == PSGDK_BF16 ? 32 : 16;
+    if (P->max_dp / kstep > 24) return PSGDK_OK;
+    // members of a factor share an XCD (workgroup b runs on XCD b % 8): per-XCD lists, longest-first packing
+    std::vector<std::vector<NlbJob>> xcd(8);
+    std::vector<int> order(P->dn.size());
+    for (size_t f = 0; f < order.size(); ++f) order[f] = (int)f;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P->dn[a].dp > P->dn[b].dp; });
+    for (int f : order) {
+        const int S = (P->dn[f].dp + 255) / 256;
+        size_t best = 0;
+        for (size_t x = 1; x < 8; ++x) if (xcd[x].size() < xcd[best].size()) best = x;
+        for (int m = 0; m < S; ++m) xcd[best].push_back(NlbJob{f, m, S, 0});
+    }
+    size_t len = 0;
+    for (auto& l : xcd) len = std::max(len, l.size());
+    if (len > 32) return PSGDK_OK;                       // more than one workgroup per CU: siblings might not be co-resident
+    int xcc[8]; bool same = false;
+    int rc = probe_xcc_map(xcc, &same);
+    if (rc) return rc;
+    { const char* e = getenv("PSGDK_NLB_SAME_XCD"); if (e && e[0] == '0') same = false; }      // (tests: the device-scope exchange)
+    P->nlb_same_xcd = same ? 1 : 0;
+    std::vector<NlbJob> jobs(8 * len, NlbJob{-1, 0, 0, 0});
+    for (size_t x = 0; x < 8; ++x)
+        for (size_t k = 0; k < xcd[x].size(); ++k) { jobs[k * 8 + x] = xcd[x][k]; jobs[k * 8 + x].xcc = xcc[x]; }
+    rc = upload(&P->d_nlb_jobs, jobs);
+    if (rc) return rc;
+    if (!P->d_nlb_sync) {
+        HIPCHK(hipMalloc((void**)&P->d_nlb_sync, P->dn.size() * sizeof(int)));
+        HIPCHK(hipMemset(P->d_nlb_sync, 0, P->dn.size() * sizeof(int)));
+    }
+    P->n_nlb_jobs = (unsigned)jobs.size();
+    P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16));
+    const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
+    HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    P->nlb_coop = true;
+    return PSGDK_OK;
+}
+static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t seed, uint64_t offset, float lr, float betaL,
+                   int add_c, int pro_iter, hipStream_t st) {
+    const unsigned F = (unsigned)P->dn.size();
+    if (P->nlb_coop) {
+        const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
+        const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; int* sync = P->d_nlb_sync;
+        unsigned char* state = P->state; unsigned char* work = P->work;
+        int same = P->nlb_same_xcd;
+        void* args[] = {&dn, &jobs, &sync, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &same};
+        HIPCHK(hipLaunchKernel(k, dim3(P->n_nlb_jobs), dim3(512), args, P->nlb_lds, st));
+        return PSGDK_OK;
+    }
+    DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, chain, noise, seed, offset, pro_iter));
+    for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[chain][p], st);
+    DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, chain, lr, betaL, add_c,
+                                     pro_iter >= 0 ? 1 : 0));
+    return PSGDK_OK;
+}
+
 static int ensure_P(psgdk_plan* plan, hipStream_t st) {
     if (!plan->p_valid) {
         if (plan->p_mode()) {      // P := Q (exprA applies every factor once; Q is symmetric in this geometry)
@@ -951,10 +1041,6 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
-        if (!qep) {
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
-        }
         if (qep) {
             // term1 = Q T1 Q^T (-> t1), term2 = c Q Q^T (-> rq); S = term1 + term2 (-> t1), D = term1 - term2 (-> r)
             launch_stage(P, P->v_qep_u, st);
@@ -962,10 +1048,8 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             launch_stage(P, P->v_qep_t2, st);
             DISPATCH_T(P, hipLaunchKernelGGL(zero_scalar_kernel, dim3((F + 63) / 64), dim3(64), 0, st, P->d_dn, P->work, (int)F, (int)DS_NF));
             DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 0));
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
         }
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr_eff, betaL, qep ? 0 : 1));
+        if ((rc = run_nlb(P, 0, nspd, seed, offset, lr_eff, betaL, qep ? 0 : 1, -1, st))) return rc;
         if (qep) {
             launch_stage(P, P->e_qupd, st);       // Q' = Q - mu (term1 - term2) Q (psgd.py:364)
             DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
@@ -974,9 +1058,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             launch_stage(P, P->g_qupd, st);
             // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
             DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset));
-            for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
-            DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1));
+            if ((rc = run_nlb(P, 1, nskh, seed, offset, lr, betaL, 1, -1, st))) return rc;
             launch_stage(P, P->g_rq, st);
             launch_stage(P, P->g_rrq, st);
         } else if (variant == PSGDK_GEOM_PRO4P) {
@@ -987,9 +1069,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
                 DISPATCH_T(P, hipLaunchKernelGGL(pro_reset_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->work));
                 DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1));
                 if (k > 0) DISPATCH_T(P, hipLaunchKernelGGL(pro_decide_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->work));
-                DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 1, nskh, seed, offset, k));
-                for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[1][p], st);
-                DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 1, lr, betaL, 1, 1));
+                if ((rc = run_nlb(P, 1, nskh, seed, offset, lr, betaL, 1, k, st))) return rc;
                 launch_stage(P, P->v_pro_rq, st);
                 launch_stage(P, P->v_pro_rrq, st);
                 launch_stage(P, P->v_pro_rrrq, st);
@@ -1140,9 +1220,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
         const dim3 grows((unsigned)(P->max_dp / 64), F);
         DISPATCH_T(P, hipLaunchKernelGGL(eq_combine_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work, 1));
         // ell = ||term1 + term2||_lb, L, mu (psgd.py:314-315 -> 46-68)
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, 0, nspd, seed, offset));
-        for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[0][p], st);
-        DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, 0, lr, betaL, 0));
+        { const int rcn = run_nlb(P, 0, nspd, seed, offset, lr, betaL, 0, -1, st); if (rcn) return rcn; }
         // Q -= mu triu(term1 - term2) Q (psgd.py:316)
         launch_stage(P, P->e_qupd, st);
         DISPATCH_T(P, hipLaunchKernelGGL(eq_commit_q_kernel<T>, dim3(16, F), dim3(256), 0, st, P->d_dn, P->state, P->work));
@@ -1260,6 +1338,17 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
                                         (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, out));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
+}
+
+int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
+    if (!plan || !value) return PSGDK_ERR_INVALID;
+    switch (what) {
+        case PSGDK_INFO_NLB_COOP: *value = plan->nlb_coop ? 1 : 0; return PSGDK_OK;
+        case PSGDK_INFO_NLB_SAME_XCD: *value = plan->nlb_coop ? plan->nlb_same_xcd : 0; return PSGDK_OK;
+        case PSGDK_INFO_DENSE_FACTORS: *value = (int64_t)plan->dn.size(); return PSGDK_OK;
+        case PSGDK_INFO_MAX_DENSE_DIM: *value = plan->max_dp; return PSGDK_OK;
+    }
+    return PSGDK_ERR_INVALID;
 }
 
 int psgdk_profile_enable(psgdk_plan* plan, int enable) {

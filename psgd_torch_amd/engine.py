@@ -263,6 +263,15 @@ class KronEngine:
                                                  float(max_avg_amp), float(max_elem_amp), self._stream()), "read_h")
         return out
 
+    def info(self):
+        """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / its exchange through one XCD's L2."""
+        out = {}
+        for name, code in (("nlb_coop", 0), ("nlb_same_xcd", 1), ("dense_factors", 2), ("max_dense_dim", 3)):
+            v = C.c_int64()
+            L.check(self.lib.psgdk_plan_info(self._plan, code, C.byref(v)), "plan_info")
+            out[name] = int(v.value)
+        return out
+
     # live profiling of the grouped-GEMM launches (bench.py)
     def profile_enable(self, on: bool = True):
         L.check(self.lib.psgdk_profile_enable(self._plan, int(on)), "profile_enable")

@@ -411,3 +411,39 @@ def test_kwns4_bf16_parameters_and_gradients():
     for p, q in zip(params, ref_p):
         assert p.dtype == torch.bfloat16
         assert relerr(p.detach().float(), q.float()) <= 2e-2, relerr(p.detach().float(), q.float())
+
+
+@pytest.mark.parametrize("dn,shape,geom", [("bf16", (768, 400), "Q0.5EQ1.5"), ("bf16", (1000, 333), "Q0.5EQ1.5"), ("bf16", (200, 70), "PRO4P"),
+                                           ("fp32", (500, 96), "Q0.5EQ1.5"), ("fp32", (130, 64), "QEP"), ("bf16", (7, 5, 40), "Q0.5EQ1.5")])
+def test_fused_norm_bound_matches_multi_launch_route(dn, shape, geom, monkeypatch):
+    """nlb_coop_kernel (start block, four products and the scalars of norm_lower_bound_spd/_skh in one cooperative launch,
+    psgd.py:46-93; both of its exchange modes: through the XCD's L2, and at device scope) against the multi-launch route
+    (init + 4 grouped GEMMs + finalize, kept for wide factors): same MFMA, same K order, same rounding points -- they may
+    differ only through the order of the fp32 row-sum atomics."""
+    amd = _amd()
+    dt = DT[dn]
+    upd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "PRO4P": amd.update_precond_kron_whiten_pro4p,
+           "QEP": amd.update_precond_kron_whiten_qep}[geom]
+    kw = dict(Scale=0.9, max_size=float("inf"), max_skew=float("inf"), dQ=geom)
+    eng = []
+    for fused, same_xcd in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("PSGDK_NLB_FUSED", fused)          # both are read when the plan is created
+        monkeypatch.setenv("PSGDK_NLB_SAME_XCD", same_xcd)
+        eng.append(amd.init_kron(torch.zeros(shape, device=DEV, dtype=dt), **kw))
+    monkeypatch.delenv("PSGDK_NLB_FUSED")
+    monkeypatch.delenv("PSGDK_NLB_SAME_XCD")
+    gen = torch.Generator().manual_seed(5)
+    for t in range(3):
+        G = (0.5 * torch.randn(shape, generator=gen)).to(dt)
+        nz = orc.KronNoise.draw(G, ["dense"] * len(shape), gen)
+        reps = 10 if geom == "PRO4P" else 1
+        skh = {(0, i): torch.cat([x] + [torch.randn(x.shape, generator=gen).to(dt) for _ in range(reps - 1)], dim=0).to(DEV)
+               for i, x in enumerate(nz.skh)}
+        noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd)}, skh)
+        for QL, exprs in eng:
+            upd(QL, exprs, G.to(DEV), lr=0.2, betaL=0.9, damping=1e-6, noise=noise)
+        tol = 1e-5 if dn == "fp32" else 2e-3
+        for i in range(len(shape)):
+            for k in (1, 2):
+                assert relerr(eng[k][0][1][i], eng[0][0][1][i]) <= tol, (t, i, k, "L", relerr(eng[k][0][1][i], eng[0][0][1][i]))
+                assert relerr(eng[k][0][0][i], eng[0][0][0][i]) <= tol, (t, i, k, "Q", relerr(eng[k][0][0][i], eng[0][0][0][i]))
