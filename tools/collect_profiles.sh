@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the evidence profiles/ holds for one build.  Run ON THE GPU BOX from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01_n'
+# writes gpurun_out/<tag>/: bench lines of every config, the rocprofv3 kernel-trace summary + one step's dispatch sequence,
+# HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
+tag=${1:-latest}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$R/gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --steps 40 --warmup 10 2> $out/bench.err | tail -1 > $out/bench.json
+python $R/bench.py --steps 40 --warmup 10 --no-roofline --no-cpu-baseline 2>> $out/bench.err | tail -1 > $out/bench_no_events.json
+for c in gpt2-medium lenet5 gpt2-small-eq vit-b-lra; do
+    python $R/bench.py --config $c --steps 30 --warmup 8 --no-cpu-baseline 2>> $out/bench.err | tail -1 > $out/bench_$c.json
+done
+rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
+db=$(find /tmp/p_stats -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $db > $out/kernel_stats.md
+python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $out/step_sequence.md
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only > /dev/null 2> $out/pmc_write.err
+python $R/tools/pmc_traffic.py $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) > $out/pmc_traffic.json
+ls -la $out
