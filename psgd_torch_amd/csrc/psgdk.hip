@@ -1395,7 +1395,7 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
-    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x128 tiling
+    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
