@@ -24,13 +24,15 @@ def run(M, N, K, batch, flags, mode="C", iters=20, label=""):
           f"tiles={tiles} rounds={tiles/slots:.2f} us/round={ms.value*1e3/rounds:.1f}", flush=True)
 
 
-for M in (162048, 65536 * 2):          # 1899 tiles = 7.4 rounds; 1536 tiles = exactly 6 rounds
+for M in (65536 * 2,):          # 1899 tiles = 7.4 rounds; 1536 tiles = exactly 6 rounds
     for big in (1024, 0):
         tag = "256x256" if big else "128x128"
         run(M, 768, 768, 1, big, label=tag + " full")
         run(M, 768, 768, 1, big | 256, label=tag + " no epilogue")
+        run(M, 768, 768, 1, big | 4096, label=tag + " epilogue without its stores")
         run(M, 768, 768, 1, big | 512, label=tag + " no main loop")
         run(M, 768, 768, 1, big | 768, label=tag + " neither (launch + tile setup)")
+        run(M, 768, 768, 1, big | 512 | 4096, label=tag + " epilogue alone, no stores")
 for big in (1024, 0):
     tag = "256x256" if big else "128x128"
     run(768, 768, 768, 62, big, mode="CT", label=tag + " 62x768^3 C+Ct full")
