@@ -734,8 +734,9 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         P->n_uinv = (unsigned)uj.size();
         if ((rc = upload(&P->d_uinv, uj))) return rc;
     }
-    // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least two full rounds of its tiles (one
-    // workgroup per CU); below that the 128 x 128 kernel's finer tiles fill the chip better.  The subspace iteration
+    // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least three full rounds of its tiles (one
+    // workgroup per CU; 560 tiles = 2.19 rounds cost three, and the 128 x 128 kernel's finer tiles then fill the chip
+    // better: -2.4 % of the GPT-2-small step with the threshold at 768 instead of 512).  The subspace iteration
     // (M = 64) and the EQ stages stay on the small tiling.  Both tilings accumulate K in the same order: same bits.
     for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1],
                      &P->g_app_b}) {
@@ -745,7 +746,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
             nb += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
         }
-        s->big = nb >= 512;
+        s->big = nb >= 768;
     }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
