@@ -896,7 +896,11 @@ static int nlb_plan_coop(psgdk_plan* P) {
     }
     size_t len = 0;
     for (auto& l : xcd) len = std::max(len, l.size());
-    if (len > 32) return PSGDK_OK;                       // more than one workgroup per CU: siblings might not be co-resident
+    // one workgroup per CU (512 threads, ~250 VGPRs): all siblings are resident only if an XCD's share fits its CUs
+    int dev = 0, cus = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < 8 || len > (size_t)(cus / 8)) return PSGDK_OK;
     int xcc[8]; bool same = false;
     int rc = probe_xcc_map(xcc, &same);
     if (rc) return rc;
