@@ -44,7 +44,10 @@ def test_gemm_kernel(dt, code, tol, big):
     lib = _lib.lib()
     st = _lib.current_stream()
     torch.manual_seed(0)
-    for (M, N, K) in ((128, 128, 64), (64, 64, 64), (192, 320, 128), (768, 768, 768), (2304, 768, 768), (64, 192, 1024), (320, 64, 192)):
+    shapes = [(128, 128, 64), (64, 64, 64), (192, 320, 128), (768, 768, 768), (2304, 768, 768), (64, 192, 1024), (320, 64, 192)]
+    if big:
+        shapes.append((44032, 768, 128))       # 516 tiles: more than two rounds of the one-workgroup-per-CU tiling
+    for (M, N, K) in shapes:
         A = torch.randn(M, K, device=DEV).to(dt)
         B = torch.randn(N, K, device=DEV).to(dt)
         Cc = torch.zeros(M, N, device=DEV, dtype=dt)
@@ -55,7 +58,7 @@ def test_gemm_kernel(dt, code, tol, big):
         Ct2 = torch.zeros(N, M, device=DEV, dtype=dt)          # transposed output only (the t-major operand order)
         _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), B.data_ptr(), None, Ct2.data_ptr(), code, M, N, K, K, K, N, M, big, st))
         assert torch.equal(Ct2, Ct) or relerr(Ct2.t(), ref) < tol, (M, N, K, "t-major")
-    for (M, K) in ((128, 64), (192, 256), (768, 2304), (320, 128)):
+    for (M, K) in ((128, 64), (192, 256), (768, 2304), (320, 128)) + (((8192, 64),) if big else ()):   # (8192: 528 upper tiles)
         A = torch.randn(M, K, device=DEV).to(dt)
         Cc = torch.full((M, M), float("nan"), device=DEV, dtype=dt)
         _lib.check(lib.psgdk_test_gemm_nt(A.data_ptr(), A.data_ptr(), Cc.data_ptr(), None, code, M, M, K, K, K, M, M, 1 | big, st))
