@@ -253,6 +253,13 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
 int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d,
                           void* stream);
 
+/* Host-only: builds the tile table the grouped GEMM would use for `n` dense problems C[M,N] (K each; sym[i] != 0: upper
+ * tiles only) on the 128x128 (big = 0) or 256x256 (big = 1) tiling and reports, per XCD queue, its tile count and its summed
+ * cost (K per tile), plus the length of the interleaved table.  No device call: the scheduling rules (queues cut at equal
+ * cumulative cost, long tiles first, block b -> XCD b % 8) can be checked without a GPU. */
+int psgdk_test_tile_queues(int n, const int32_t* M, const int32_t* N, const int32_t* K, const int32_t* sym, int big,
+                           int64_t* queue_tiles, int64_t* queue_cost, int64_t* table_len);
+
 #ifdef __cplusplus
 }
 #endif

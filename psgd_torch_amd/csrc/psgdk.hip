@@ -1455,6 +1455,33 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     return rc;
 }
 
+int psgdk_test_tile_queues(int n, const int32_t* M, const int32_t* N, const int32_t* K, const int32_t* sym, int big,
+                           int64_t* queue_tiles, int64_t* queue_cost, int64_t* table_len) {
+    if (n <= 0 || !M || !N || !K || !queue_tiles || !queue_cost || !table_len) return PSGDK_ERR_INVALID;
+    TileTableBuilder tb;
+    tb.bm = big ? GEMM_BIG_BM : GEMM_BM;
+    tb.bn = big ? GEMM_BIG_BN : GEMM_BN;
+    std::vector<GemmProblem> probs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (M[i] <= 0 || N[i] <= 0 || K[i] <= 0) return PSGDK_ERR_INVALID;
+        probs[i].M = M[i]; probs[i].N = N[i]; probs[i].K = K[i];
+        probs[i].flags = (sym && sym[i]) ? GF_SYM : 0;
+        tb.add_problem(i, probs[i]);
+    }
+    const std::vector<GemmTile> table = tb.finish();
+    *table_len = (int64_t)table.size();
+    for (int x = 0; x < 8; ++x) { queue_tiles[x] = 0; queue_cost[x] = 0; }
+    // read the queues back from the table the kernel would see: entry b belongs to XCD b % 8
+    for (size_t b = 0; b < table.size(); ++b) {
+        const GemmTile& t = table[b];
+        if (t.prob < 0) continue;
+        if (t.prob >= n) return PSGDK_ERR_STATE;
+        queue_tiles[b % 8] += 1;
+        queue_cost[b % 8] += probs[t.prob].K;
+    }
+    return PSGDK_OK;
+}
+
 int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d, void* stream) {
     if (!Y || !U || (!out_nat && !out_t) || rows <= 0 || d <= 0 || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;

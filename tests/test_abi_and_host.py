@@ -158,3 +158,30 @@ def test_flop_model_matches_survey():
     assert sum(__import__("math").prod(s) for s in bench.gpt2_shapes()) == 124475904
     s2 = sum(orc.kron_step_flops(s)[0] for s in bench.gpt2_shapes())
     assert abs(s2 - step) / step < 1e-12
+
+
+@pytest.mark.parametrize("big", [0, 1])
+def test_gemm_tile_table_queues_are_level(lib, big):
+    """The grouped GEMM's tile table (host code, no device call): every tile appears once, workgroup b belongs to XCD
+    b % 8, and the eight queues are cut at equal cumulative cost -- the GPT-2-small apply stage (12 blocks x 4 matrices, wte,
+    wpe; dense dim last) that greedy 48-tile chunks left 8.7 % out of balance (one extra round of tiles for the launch)."""
+    rows = [50304, 1024] + [2304, 768, 3072, 3072] * 12            # X P with P 768 x 768: M = rows, N = K = 768
+    n = len(rows)
+    arr = lambda v: (C.c_int32 * n)(*v)
+    qt, qc, tl = (C.c_int64 * 8)(), (C.c_int64 * 8)(), C.c_int64()
+    rc = lib.psgdk_test_tile_queues(n, arr(rows), arr([768] * n), arr([768] * n), arr([0] * n), big, qt, qc, C.byref(tl))
+    assert rc == 0
+    bm = 256 if big else 128
+    expect = sum(-(-r // bm) * (768 // bm) for r in rows)
+    assert sum(qt) == expect                                     # nothing lost, nothing doubled
+    assert max(qt) - min(qt) <= 1, list(qt)                      # level queues (all tiles cost K = 768 here)
+    assert tl.value <= 8 * max(qt)                               # interleaved table: at most one partial row of padding
+    # mixed K (the mode Grams): costs, not counts, are levelled -- within one tile of the longest K
+    Ks = [768, 3072, 2304, 768] * 6
+    m = len(Ks)
+    arr = lambda v: (C.c_int32 * m)(*v)
+    rc = lib.psgdk_test_tile_queues(m, arr([768] * m), arr([768] * m), arr(Ks), arr([1] * m), big, qt, qc, C.byref(tl))
+    assert rc == 0
+    per = (768 // bm) * (768 // bm + 1) // 2 if bm == 256 else 21  # upper tiles of a 768 x 768 symmetric problem
+    assert sum(qt) == per * m
+    assert max(qc) - min(qc) <= 2 * max(Ks), list(qc)
