@@ -226,7 +226,9 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
 
 /* ---- introspection (bench.py / tests; no reference counterpart): how the plan runs.  NLB_COOP: the norm lower bounds
  * (psgd.py:46-93) run as one cooperative launch per bound instead of start block + 4 grouped-GEMM products + scalars (set at
- * psgdk_plan_bind); NLB_SAME_XCD: its workgroups exchange through their XCD's L2 (placement verified by a probe). */
+ * psgdk_plan_bind); NLB_SAME_XCD: its workgroups exchange through their XCD's L2 (placement verified by a probe).  When
+ * NLB_COOP is set, do not run the updates of two plans concurrently on different streams of one device: each cooperative launch
+ * needs a CU for every one of its workgroups at the same time. */
 #define PSGDK_INFO_NLB_COOP 0
 #define PSGDK_INFO_NLB_SAME_XCD 1
 #define PSGDK_INFO_DENSE_FACTORS 2
