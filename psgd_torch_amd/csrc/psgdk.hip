@@ -1524,7 +1524,8 @@ struct psgdk_lra {
 extern "C" {
 
 int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype) {
-    if (!out || N <= 0 || r < 0 || r > LRA_RMAX || (r > 0 && r >= N) || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (!out || N <= 0 || r < 0 || (r > 0 && r >= N) || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;        // valid upstream (any rank); the kernels hold r <= 16
     psgdk_lra* L = new psgdk_lra();
     L->N = N; L->r = r; L->dtype = dtype; L->esz = dtype == PSGDK_BF16 ? 2 : 4;
     size_t wo = 0;
