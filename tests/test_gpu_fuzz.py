@@ -36,8 +36,19 @@ N_CASES = int(os.environ.get("PSGDK_FUZZ_CASES", "40"))        # raise for a lon
 
 @pytest.mark.parametrize("seed", list(range(N_CASES)))
 def test_random_case_matches_oracle(seed):
+    _run_case(seed, *_case(seed))
+
+
+@pytest.mark.parametrize("shape,geom", [((96, 5000), "Q0.5EQ1.5"), ((5000, 96), "Q0.5EQ1.5"), ((70, 9000), "QEQ"), ((4500, 128), "PRO4P")])
+def test_long_contracted_dimension_split_k(shape, geom):
+    """A mode Gram whose contracted extent exceeds 4096 is computed as split-K partial sums (fp32 slabs) and finished by
+    splitk_reduce_sym_kernel -- the wte path of GPT-2 (K = 50304).  The long dimension is kept diagonal (max_size), so the
+    dense factor is small and the oracle stays cheap; K = 5056 / 9024 / 4544 gives 2 / 3 / 2 slabs of 3072."""
+    _run_case(900 + len(geom) + shape[0], shape, float("inf"), 4096.0, geom)
+
+
+def _run_case(seed, shape, max_skew, max_size, geom):
     import psgd_torch_amd as amd
-    shape, max_skew, max_size, geom = _case(seed)
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
     upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
                "QEQ": amd.update_precond_kron_whiten_qeq, "QUAD": amd.update_precond_kron_whiten_quad,
