@@ -435,6 +435,13 @@ def test_fused_norm_bound_matches_multi_launch_route(dn, shape, geom, monkeypatc
         eng.append(amd.init_kron(torch.zeros(shape, device=DEV, dtype=dt), **kw))
     monkeypatch.delenv("PSGDK_NLB_FUSED")
     monkeypatch.delenv("PSGDK_NLB_SAME_XCD")
+    # the comparison is only worth something if the engines really took different routes: the cooperative kernel holds
+    # factors up to 768 (bf16) / 384 (fp32) wide, wider plans stay on the multi-launch route whatever the switches say
+    widest = -(-max(shape) // 64) * 64
+    coop_expected = int(widest <= (768 if dn == "bf16" else 384))
+    infos = [e[1][0].info() for e in eng]
+    assert [i["nlb_coop"] for i in infos] == [0, coop_expected, coop_expected], infos
+    assert infos[2]["nlb_same_xcd"] == 0
     gen = torch.Generator().manual_seed(5)
     for t in range(3):
         G = (0.5 * torch.randn(shape, generator=gen)).to(dt)
