@@ -416,7 +416,7 @@ def test_kwns4_bf16_parameters_and_gradients():
         assert relerr(p.detach().float(), q.float()) <= 2e-2, relerr(p.detach().float(), q.float())
 
 
-@pytest.mark.parametrize("dn,shape,geom", [("bf16", (768, 400), "Q0.5EQ1.5"), ("bf16", (1000, 333), "Q0.5EQ1.5"), ("bf16", (200, 70), "PRO4P"),
+@pytest.mark.parametrize("dn,shape,geom", [("bf16", (768, 400), "Q0.5EQ1.5"), ("bf16", (1000, 333), "Q0.5EQ1.5"), ("bf16", (200, 70), "PRO4P"), ("fp32", (380, 70), "PRO4P"),
                                            ("fp32", (500, 96), "Q0.5EQ1.5"), ("fp32", (130, 64), "QEP"), ("bf16", (7, 5, 40), "Q0.5EQ1.5")])
 def test_fused_norm_bound_matches_multi_launch_route(dn, shape, geom, monkeypatch):
     """nlb_coop_kernel (start block, four products and the scalars of norm_lower_bound_spd/_skh in one cooperative launch,
@@ -452,7 +452,9 @@ def test_fused_norm_bound_matches_multi_launch_route(dn, shape, geom, monkeypatc
         noise = ([nz.g_noise.to(DEV)], {(0, i): x.to(DEV) for i, x in enumerate(nz.spd)}, skh)
         for QL, exprs in eng:
             upd(QL, exprs, G.to(DEV), lr=0.2, betaL=0.9, damping=1e-6, noise=noise)
-        tol = 1e-5 if dn == "fp32" else 2e-3
+        # (PRO4P rotates by a NORMALISED P - P^T, i.e. by rounding noise once P is nearly symmetric: last-bit differences of the
+        #  bound are amplified -- fp32 2e-3 as in the fuzz test; bf16 only on the small case that is not on that edge)
+        tol = (2e-3 if geom == "PRO4P" else 1e-5) if dn == "fp32" else 2e-3
         for i in range(len(shape)):
             for k in (1, 2):
                 assert relerr(eng[k][0][1][i], eng[0][0][1][i]) <= tol, (t, i, k, "L", relerr(eng[k][0][1][i], eng[0][0][1][i]))
