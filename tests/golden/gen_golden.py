@@ -509,7 +509,7 @@ def gen_kwns4():
 # ------------------------------------------------------------------------------------------------
 # D. LRA functional + LRAWhiten.step
 # ------------------------------------------------------------------------------------------------
-def gen_lra_case(name, N, r, dtypes, T=4, lr=0.1, betaL=0.9, damping=1e-9, seed=0):
+def gen_lra_case(name, N, r, dtypes, T=4, lr=0.1, betaL=0.9, damping=1e-9, seed=0, prefix="lra_"):
     out = {"N": np.asarray(N), "r": np.asarray(r), "T": np.asarray(T), "lr": np.asarray(lr),
            "betaL": np.asarray(betaL), "damping": np.asarray(damping)}
     g = torch.Generator().manual_seed(70 + seed)
@@ -540,7 +540,7 @@ def gen_lra_case(name, N, r, dtypes, T=4, lr=0.1, betaL=0.9, damping=1e-9, seed=
             out[f"{dn}_t{t}_U"], out[f"{dn}_t{t}_V"], out[f"{dn}_t{t}_d"] = npy(UVd[0]), npy(UVd[1]), npy(UVd[2])
             for k, nm in enumerate(("Lu", "Lv", "Ld")):
                 out[f"{dn}_t{t}_{nm}"] = npy(Luvd[k])
-    save("lra_" + name, out)
+    save(prefix + name, out)
 
 
 def gen_lrawhiten_case(name, T=4, seed=0, **kw):
@@ -582,6 +582,8 @@ def gen_lra():
     gen_lra_case("n257_r1", 257, 1, ("fp64", "fp32"), T=4, lr=0.3, betaL=0.5, damping=1e-3, seed=3)
     gen_lra_case("n300_r0", 300, 0, ("fp64", "fp32", "bf16"), T=3, seed=4)          # rank 0 = diagonal preconditioner
     gen_lra_case("n1000_r16", 1000, 16, ("fp32", "bf16"), T=3, seed=5)               # the largest rank the HIP kernels hold
+    # beyond it: pins the ORACLE only (prefix keeps it out of the GPU tests' lra_* sweep) -- the fixture for the next rank step
+    gen_lra_case("n600_r32", 600, 32, ("fp64", "fp32"), T=3, seed=6, prefix="lrabig_")
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)
