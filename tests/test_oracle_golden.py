@@ -209,7 +209,7 @@ def test_kwns4_step(name):
                 assert relerr(ell, z[f"t{t}_p{i}_L{j}"]) <= TOL[dn], (name, t, i, j, "L")
 
 
-@pytest.mark.parametrize("name", golden_names("lra_"))
+@pytest.mark.parametrize("name", golden_names("lra_") + golden_names("lrabig_"))      # lrabig_: rank 32, oracle only
 def test_lra_update_and_apply(name):
     z = load(name)
     Tn = int(z["T"])
