@@ -336,8 +336,7 @@ def main():
                    "parallelism_probe_ms": ({k: v * 1e3 for k, v in timing.items()} if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                    "apply_only_ms_per_step": apply_only_ms,
-                   "norm_bound_route": ("cooperative launch" + (" (L2 exchange)" if engines[0].info()["nlb_same_xcd"] else " (device-scope exchange)"))
-                                       if nlb_coop else "grouped-GEMM products"},
+                   "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products"},
     }
     if world == 1 and gemm_launches and prof_steps:
         launches_per_step = gemm_launches / prof_steps

@@ -38,7 +38,11 @@ enum {
     PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
     PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (tensors with > 8 dims, LRA rank > 16) */
     PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
-    PSGDK_ERR_STATE = 4        /* call order violated (e.g. arenas not bound) */
+    PSGDK_ERR_STATE = 4,       /* call order violated (e.g. arenas not bound) */
+    PSGDK_ERR_NLB_TIMEOUT = 5  /* returned ONCE by the first psgdk_update_precond_* call after a cooperative norm-bound launch of an
+                                  earlier call gave up waiting for a sibling workgroup (bounded spin): the dense factors concerned
+                                  skipped that one preconditioner update (state stays valid), and the plan has switched to the
+                                  multi-launch route for good.  Nothing was enqueued by the call that returns it: repeat the call. */
 };
 
 /* element types */
@@ -226,11 +230,11 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
 
 /* ---- introspection (bench.py / tests; no reference counterpart): how the plan runs.  NLB_COOP: the norm lower bounds
  * (psgd.py:46-93) run as one cooperative launch per bound instead of start block + 4 grouped-GEMM products + scalars (set at
- * psgdk_plan_bind); NLB_SAME_XCD: its workgroups exchange through their XCD's L2 (placement verified by a probe).  When
- * NLB_COOP is set, do not run the updates of two plans concurrently on different streams of one device: each cooperative launch
- * needs a CU for every one of its workgroups at the same time. */
+ * psgdk_plan_bind; cleared for good when a launch times out, see PSGDK_ERR_NLB_TIMEOUT); NLB_FALLBACKS: how often that
+ * happened.  The workgroups of a cooperative launch exchange their slabs with a placement-independent device-scope protocol
+ * and bound every spin, so concurrent work on other streams can delay a launch but neither hang nor corrupt it. */
 #define PSGDK_INFO_NLB_COOP 0
-#define PSGDK_INFO_NLB_SAME_XCD 1
+#define PSGDK_INFO_NLB_FALLBACKS 1
 #define PSGDK_INFO_DENSE_FACTORS 2
 #define PSGDK_INFO_MAX_DENSE_DIM 3   /* padded to a multiple of 64 */
 int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
@@ -243,6 +247,14 @@ int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches
 
 /* ---- kernel-level test hooks (used by tests/ and bench.py only) ------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T on padded row-major operands (all dims multiples of 64), same kernel the engine uses. */
+/* test hook: ONE norm lower bound (psgd.py:46-93; chain 0 = spd on term1, 1 = skh on R) of every dense factor on the plan's
+ * CURRENT work arena (i.e. after a psgdk_update_precond_q0p5eq1p5 call), by the cooperative launch (route 1) or the multi-launch
+ * route (route 0), Philox noise (seed, offset).  Copies the four products' row sums of squares ([F][4][32] fp32) to out_vsq and
+ * the last subspace block ([F][32][max_dense_dim] of the preconditioner dtype, rows padded with zeros) to out_v (device
+ * pointers, either may be NULL).  inject_fault != 0 makes member 1 of every multi-member factor skip its arrivals, to exercise
+ * the timeout path (route 1 only). */
+int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
+                   int inject_fault, void* stream);
 int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,
                        int ldb, int ldc, int ldct, int symmetric, void* stream);
 /* times `iters` launches of a batch of identical dense problems (contiguous operands) with hipEvents: avg ms/launch */

@@ -62,9 +62,12 @@ struct psgdk_plan {
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
     int* d_balance = nullptr; float* d_balnorm = nullptr;
     int max_dp = 0;
-    int nlb_same_xcd = 0;             // members of a factor verified to share an XCD: exchange through its L2
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
-    NlbJob* d_nlb_jobs = nullptr; int* d_nlb_sync = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
+    NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
+    // error word of the cooperative kernels: host-mapped pinned memory, so that the host can look at it WITHOUT synchronising
+    // (read at the start of every update call; see nlb_check_error)
+    volatile unsigned* h_err = nullptr; unsigned* d_err = nullptr;
+    int64_t nlb_fallbacks = 0;        // how often a timeout moved this plan to the multi-launch route (0 or 1)
     bool nlb_unfused = false;        // PSGDK_NLB_FUSED=0 at plan creation: keep the multi-launch route (tests compare the two)
     bool p_valid = false;
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
@@ -101,7 +104,8 @@ struct psgdk_plan {
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
-        fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_sync);
+        fr(d_uinv); fr(d_nlb_jobs);
+        if (h_err) (void)hipHostFree((void*)h_err);
     }
 };
 
@@ -276,6 +280,8 @@ const char* psgdk_strerror(int status) {
         case PSGDK_ERR_UNSUPPORTED: return "unsupported (not built yet)";
         case PSGDK_ERR_HIP: return "HIP runtime error (see psgdk_last_hip_error)";
         case PSGDK_ERR_STATE: return "call order violated";
+        case PSGDK_ERR_NLB_TIMEOUT: return "a cooperative norm-bound launch timed out waiting for a sibling workgroup; the affected "
+                                           "factors skipped that update, the plan now uses the multi-launch route -- repeat the call";
         default: return "unknown status";
     }
 }
@@ -861,29 +867,13 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
 // factor fits its register budget (bf16: dp <= 768, fp32: dp <= 384) and all workgroups are resident at once; otherwise start
 // block, four grouped-GEMM products and the scalars as separate launches.  PSGDK_NLB_FUSED=0 at plan creation forces the
 // latter (the tests compare the two).
-// Does workgroup b of a launch run on the XCD of b % 8?  Probed once per process; xcc[x] = hardware XCC id of slot x.
-static int probe_xcc_map(int (&xcc)[8], bool* consistent) {
-    static int cached = -1, map[8];
-    if (cached < 0) {
-        int* d = nullptr; int h[64];
-        HIPCHK(hipMalloc((void**)&d, sizeof(h)));
-        hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, nullptr, d);
-        HIPCHK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-        (void)hipFree(d);
-        cached = 1;
-        for (int b = 0; b < 64; ++b) if (h[b] != h[b % 8]) cached = 0;
-        for (int x = 0; x < 8; ++x) map[x] = h[x];
-    }
-    for (int x = 0; x < 8; ++x) xcc[x] = map[x];
-    *consistent = cached == 1;
-    return PSGDK_OK;
-}
 static int nlb_plan_coop(psgdk_plan* P) {
     P->nlb_coop = false;
-    if (P->nlb_unfused || P->dn.empty()) return PSGDK_OK;
+    if (P->dn.empty()) return PSGDK_OK;
     const int kstep = P->dtype == PSGDK_BF16 ? 32 : 16;
     if (P->max_dp / kstep > 24) return PSGDK_OK;
-    // members of a factor share an XCD (workgroup b runs on XCD b % 8): per-XCD lists, longest-first packing
+    // members of a factor are dealt to one XCD (workgroup b is observed to run on XCD b % 8; speed only -- their slabs of A
+    // then share an L2 -- the exchange protocol does not depend on it): per-XCD lists, longest-first packing
     std::vector<std::vector<NlbJob>> xcd(8);
     std::vector<int> order(P->dn.size());
     for (size_t f = 0; f < order.size(); ++f) order[f] = (int)f;
@@ -901,36 +891,33 @@ static int nlb_plan_coop(psgdk_plan* P) {
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus < 8 || len > (size_t)(cus / 8)) return PSGDK_OK;
-    int xcc[8]; bool same = false;
-    int rc = probe_xcc_map(xcc, &same);
-    if (rc) return rc;
-    { const char* e = getenv("PSGDK_NLB_SAME_XCD"); if (e && e[0] == '0') same = false; }      // (tests: the device-scope exchange)
-    P->nlb_same_xcd = same ? 1 : 0;
     std::vector<NlbJob> jobs(8 * len, NlbJob{-1, 0, 0, 0});
     for (size_t x = 0; x < 8; ++x)
-        for (size_t k = 0; k < xcd[x].size(); ++k) { jobs[k * 8 + x] = xcd[x][k]; jobs[k * 8 + x].xcc = xcc[x]; }
-    rc = upload(&P->d_nlb_jobs, jobs);
+        for (size_t k = 0; k < xcd[x].size(); ++k) jobs[k * 8 + x] = xcd[x][k];
+    int rc = upload(&P->d_nlb_jobs, jobs);
     if (rc) return rc;
-    if (!P->d_nlb_sync) {
-        HIPCHK(hipMalloc((void**)&P->d_nlb_sync, P->dn.size() * sizeof(int)));
-        HIPCHK(hipMemset(P->d_nlb_sync, 0, P->dn.size() * sizeof(int)));
+    if (!P->h_err) {
+        void* h = nullptr; void* d = nullptr;
+        HIPCHK(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        std::memset(h, 0, 64);
+        HIPCHK(hipHostGetDevicePointer(&d, h, 0));
+        P->h_err = (volatile unsigned*)h; P->d_err = (unsigned*)d;
     }
     P->n_nlb_jobs = (unsigned)jobs.size();
     P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16));
     const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
     HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    P->nlb_coop = true;
+    P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
 }
 static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t seed, uint64_t offset, float lr, float betaL,
-                   int add_c, int pro_iter, hipStream_t st) {
+                   int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0) {
     const unsigned F = (unsigned)P->dn.size();
-    if (P->nlb_coop) {
+    if (route < 0 ? P->nlb_coop : (route == 1)) {
         const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
-        const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; int* sync = P->d_nlb_sync;
+        const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
-        int same = P->nlb_same_xcd;
-        void* args[] = {&dn, &jobs, &sync, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &same};
+        void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
         HIPCHK(hipLaunchKernel(k, dim3(P->n_nlb_jobs), dim3(512), args, P->nlb_lds, st));
         return PSGDK_OK;
     }
@@ -938,6 +925,19 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
     for (int p = 0; p < 4; ++p) launch_stage(P, P->g_nlb[chain][p], st);
     DISPATCH_T(P, hipLaunchKernelGGL(nlb_finalize_kernel<T>, dim3(F), dim3(64), 0, st, P->d_dn, P->state, P->work, chain, lr, betaL, add_c,
                                      pro_iter >= 0 ? 1 : 0));
+    return PSGDK_OK;
+}
+
+// Did a cooperative norm-bound launch of an EARLIER call give up waiting for a sibling (its factors skipped that update; the
+// state is valid)?  Non-blocking: the kernels write the word straight into host memory.  Reported once; the plan then stays on
+// the multi-launch route.
+static int nlb_check_error(psgdk_plan* P) {
+    if (P->h_err && *P->h_err != 0u) {
+        *P->h_err = 0u;
+        P->nlb_coop = false;
+        ++P->nlb_fallbacks;
+        return PSGDK_ERR_NLB_TIMEOUT;
+    }
     return PSGDK_OK;
 }
 
@@ -973,6 +973,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
     int rc;
+    if ((rc = nlb_check_error(P))) return rc;
     if (noise) {
         HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
         if (F) {
@@ -1150,6 +1151,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
+    { const int rce = nlb_check_error(P); if (rce) return rce; }
     if (noise) {
         HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
         if (F) {
@@ -1349,7 +1351,7 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
     if (!plan || !value) return PSGDK_ERR_INVALID;
     switch (what) {
         case PSGDK_INFO_NLB_COOP: *value = plan->nlb_coop ? 1 : 0; return PSGDK_OK;
-        case PSGDK_INFO_NLB_SAME_XCD: *value = plan->nlb_coop ? plan->nlb_same_xcd : 0; return PSGDK_OK;
+        case PSGDK_INFO_NLB_FALLBACKS: *value = plan->nlb_fallbacks; return PSGDK_OK;
         case PSGDK_INFO_DENSE_FACTORS: *value = (int64_t)plan->dn.size(); return PSGDK_OK;
         case PSGDK_INFO_MAX_DENSE_DIM: *value = plan->max_dp; return PSGDK_OK;
     }
@@ -1384,6 +1386,24 @@ int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t o
     const int grid = (int)std::min<int64_t>((n + block - 1) / block, 256 * 8);
     hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, out, dtype, n, seed, offset,
                        stream_id);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
+                   int inject_fault, void* stream) {
+    if (!plan || (chain != 0 && chain != 1) || (route != 0 && route != 1)) return PSGDK_ERR_INVALID;
+    if (!plan->state || plan->dn.empty()) return PSGDK_ERR_STATE;
+    if (route == 1 && !plan->d_nlb_jobs) return PSGDK_ERR_STATE;        // the plan has no cooperative launch (wide factors)
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned F = (unsigned)P->dn.size();
+    // what a real update zeroes before the bound: this chain's row sums and arrival counter
+    hipLaunchKernelGGL(test_nlb_reset_kernel, dim3(F), dim3(64), 0, st, P->d_dn, P->work, chain);
+    int rc = run_nlb(P, chain, nullptr, seed, offset, 0.1f, 0.9f, 1, -1, st, route, inject_fault ? 4096 : 0);
+    if (rc) return rc;
+    DISPATCH_T(P, hipLaunchKernelGGL(test_nlb_collect_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, chain, P->max_dp, out_vsq,
+                                     (T*)out_v));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }

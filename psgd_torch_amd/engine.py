@@ -29,6 +29,39 @@ def _on_device(fn):
     return wrapper
 
 
+def _numel(shape) -> int:
+    n = 1
+    for x in shape:
+        n *= int(x)
+    return n
+
+
+def _check_tensors(what: str, tensors: Sequence[torch.Tensor], numels: Sequence[int], device) -> torch.dtype:
+    """The library takes raw device pointers and walks them in logical-contiguous order with ONE element type per call: a
+    strided view (channels_last weight, transposed / tied view), a tensor on another device or a mixed-dtype list would be
+    read and written wrongly without any error -- the reference's `p.subtract_(h.view_as(p))` is stride-safe
+    (wrapped_as_torch_optimizer_for_ddp.py:157), raw pointers are not.  Refuse instead of corrupting."""
+    if len(tensors) != len(numels):
+        raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}: expected {len(numels)} tensors, got {len(tensors)}")
+    dt = tensors[0].dtype if len(tensors) else torch.float32
+    for k, (t, n) in enumerate(zip(tensors, numels)):
+        if not isinstance(t, torch.Tensor):
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] is not a tensor")
+        if t.device != device:
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] lives on {t.device}, the engine on {device}")
+        if t.dtype != dt:
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] has dtype {t.dtype} but {what}[0] has {dt}: one engine call "
+                                                    "takes one element type (bucket the tensors by dtype, as KWNS4 does)")
+        if t.numel() != n:
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] has {t.numel()} elements, the plan expects {n}")
+        if not t.is_contiguous():
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] is not contiguous (strides {tuple(t.stride())} for shape "
+                                                    f"{tuple(t.shape)}): the HIP engine addresses tensors by raw pointer in "
+                                                    "logical-contiguous order")
+    L.dtype_code(dt)       # bf16 / fp32 only
+    return dt
+
+
 class FlatApply:
     """psgdk_flat_*: the parameter update of the sharded path's exchange step (all tensors, one launch)."""
 
@@ -38,6 +71,9 @@ class FlatApply:
         if self.device.type != "cuda":
             raise L.PsgdkError(L.PSGDK_ERR_INVALID, "FlatApply needs a ROCm device (cuda:N); there is no CPU fallback")
         self.n = len(numels)
+        self.numels = [int(x) for x in numels]
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._h = C.c_void_p()
         na = (C.c_int64 * self.n)(*[int(x) for x in numels])
         oa = (C.c_int64 * self.n)(*[int(x) for x in offsets])
@@ -53,6 +89,9 @@ class FlatApply:
             pass
 
     def apply(self, params: Sequence[torch.Tensor], flat: torch.Tensor, lr: float, decoupled_wd: float):
+        _check_tensors("params", params, self.numels, self.device)
+        if not flat.is_contiguous() or flat.device != self.device:
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, "the gathered buffer must be a contiguous tensor on the engine's device")
         pa = L.ptr_array(params)
         self._keep = (pa, list(params), flat)
         with torch.cuda.device(self.device):
@@ -85,6 +124,7 @@ class KronEngine:
         self.code = L.dtype_code(precond_dtype)
         self.shapes = [tuple(int(x) for x in s) for s in shapes]
         self.n = len(self.shapes)
+        self.numels = [_numel(s) for s in self.shapes]
         self.use_momentum = bool(use_momentum)
         ndim = (C.c_int32 * self.n)(*[len(s) for s in self.shapes])
         flat = [d for s in self.shapes for d in s]
@@ -189,10 +229,9 @@ class KronEngine:
                    coupled_wd: float = 0.0, beta: float = 0.0, keep_grad: bool = False, damp: Optional[dict] = None):
         """damp = dict(source, damping, seed, offset): fuse the damped input of an update_precond call that will follow
         with exactly these arguments (Philox noise only) into this pass."""
-        assert len(grads) == self.n
-        for g, s in zip(grads, self.shapes):
-            if not g.is_contiguous() or g.device != self.device:
-                raise L.PsgdkError(L.PSGDK_ERR_INVALID, "gradients must be contiguous tensors on the engine's device")
+        _check_tensors("grads", grads, self.numels, self.device)
+        if params is not None:
+            _check_tensors("params", params, self.numels, self.device)
         ga = L.ptr_array(grads)
         pa = L.ptr_array(params) if params is not None else None
         self._keep = [ga, pa, list(grads)]
@@ -231,16 +270,29 @@ class KronEngine:
         if balance_mask is not None:
             bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
         if self.geometry == L.GEOM_QEP:      # balances every tensor itself, first (psgd.py:346-347): no gate argument
-            L.check(self.lib.psgdk_update_precond_qep(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr,
-                                                      int(seed), int(offset), self._stream()), "update_precond")
+            self._checked_update(lambda: self.lib.psgdk_update_precond_qep(self._plan, int(source), float(lr), float(betaL),
+                                                                           float(damping), nz_ptr, int(seed), int(offset), self._stream()))
             self._keep_noise = keep
             return
         fn = {L.GEOM_Q0P5EQ1P5: self.lib.psgdk_update_precond_q0p5eq1p5, L.GEOM_EQ: self.lib.psgdk_update_precond_eq,
               L.GEOM_QEQ: self.lib.psgdk_update_precond_qeq, L.GEOM_QUAD: self.lib.psgdk_update_precond_quad,
               L.GEOM_QUAD4P: self.lib.psgdk_update_precond_quad4p, L.GEOM_PRO4P: self.lib.psgdk_update_precond_pro4p}[self.geometry]
-        L.check(fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed), int(offset), bm,
-                   self._stream()), "update_precond")
+        self._checked_update(lambda: fn(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed),
+                                        int(offset), bm, self._stream()))
         self._keep_noise = keep
+
+    def _checked_update(self, call):
+        """PSGDK_ERR_NLB_TIMEOUT is the library reporting -- once, before enqueueing anything -- that a cooperative norm-bound
+        launch of an EARLIER update gave up waiting for a sibling workgroup: the factors concerned skipped that one
+        preconditioner update (state valid) and the plan now runs the multi-launch route.  Say so loudly, then repeat the call."""
+        status = call()
+        if status == L.PSGDK_ERR_NLB_TIMEOUT:
+            import warnings
+            warnings.warn("psgd_torch_amd: a cooperative norm-bound launch timed out waiting for a sibling workgroup (GPU shared "
+                          "with long-running kernels?); the affected Kron factors skipped one preconditioner update and this "
+                          "engine now uses the multi-launch norm-bound route", RuntimeWarning, stacklevel=3)
+            status = call()
+        L.check(status, "update_precond")
 
     @_on_device
     def precond_grad(self, source: int):
@@ -249,6 +301,7 @@ class KronEngine:
     @_on_device
     def apply_update(self, params: Sequence[torch.Tensor], lr: float, decoupled_wd: float, max_avg_amp: float,
                      max_elem_amp: float):
+        _check_tensors("params", params, self.numels, self.device)
         pa = L.ptr_array(params)
         self._keep_p = [pa, list(params)]
         L.check(self.lib.psgdk_apply_update(self._plan, pa, L.dtype_code(params[0].dtype), float(lr), float(decoupled_wd),
@@ -259,14 +312,16 @@ class KronEngine:
                           max_elem_amp: float = 10.0) -> torch.Tensor:
         if out is None:
             out = torch.empty(self.shapes[t], dtype=self.dtype, device=self.device)
+        _check_tensors("out", [out], [self.numels[t]], self.device)
         L.check(self.lib.psgdk_read_precond_grad(self._plan, t, out.data_ptr(), L.dtype_code(out.dtype), int(clip),
                                                  float(max_avg_amp), float(max_elem_amp), self._stream()), "read_h")
         return out
 
     def info(self):
-        """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / its exchange through one XCD's L2."""
+        """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / how often a timeout switched it off."""
         out = {}
-        for name, code in (("nlb_coop", 0), ("nlb_same_xcd", 1), ("dense_factors", 2), ("max_dense_dim", 3)):
+        for name, code in (("nlb_coop", L.INFO_NLB_COOP), ("nlb_fallbacks", L.INFO_NLB_FALLBACKS),
+                           ("dense_factors", L.INFO_DENSE_FACTORS), ("max_dense_dim", L.INFO_MAX_DENSE_DIM)):
             v = C.c_int64()
             L.check(self.lib.psgdk_plan_info(self._plan, code, C.byref(v)), "plan_info")
             out[name] = int(v.value)

@@ -246,8 +246,8 @@ class KWNS4(torch.optim.Optimizer):
             b.flat_apply = self._engine_factory.FlatApply(numels, h_offsets, p0.device)
         self._buckets[key] = b
         pending = getattr(self, "_pending_restore", None)
-        if pending:                      # load_state_dict() was called before the buckets existed
-            self._restore_bucket(b, pending.pop(0))
+        if pending and self._key_str(key) in pending:      # load_state_dict() was called before this bucket existed
+            self._restore_bucket(b, pending.pop(self._key_str(key)))
         return b
 
     @torch.no_grad()
@@ -319,40 +319,71 @@ class KWNS4(torch.optim.Optimizer):
             self._resync(b, plist)
 
     def _resync(self, b, plist):
+        # replicated mode: every rank holds the same bucket over the same tensors, so the whole state arena (Q, Q^T, diagonal
+        # factors, L, ema of all parameters) travels as ONE broadcast instead of the reference's per-tensor ones
         for p in plist:
             torch.distributed.broadcast(p, src=0)
         if b.engine is not None:
             torch.distributed.broadcast(b.engine.state_arena, src=0)
+            b.engine.state_changed()      # the cached P = Q^T Q (work arena) belongs to the pre-resync factors
 
     # ------------------------------------------------------------------------------------------------------------------
     # checkpoint / resume.  The reference offers none that works: its state holds opt_einsum expression objects and its
     # private RNG states live outside `state`.  Here the whole engine state of a bucket is one arena
     # tensor (Q, Qt, diagonal factors, L, ema) plus two counters and the host gate generator's state.
+    @staticmethod
+    def _key_str(key) -> str:
+        """Bucket key (group index, param dtype, grad dtype, device[, "p", position]) as a string that survives pickling."""
+        return "|".join(str(x) for x in key)
+
     def state_dict(self):
-        buckets = []
+        buckets = {}
         for key, b in self._buckets.items():
-            buckets.append({
+            buckets[self._key_str(key)] = {
                 "group": key[0], "n_params": len(b.params), "owned": list(b.owned), "step": b.step,
                 "arena": b.engine.state_arena.detach().clone().cpu() if b.engine is not None else None,
-            })
-        return {"psgdk_version": 1, "state": {},      # per-parameter state lives in the bucket arenas below
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+            }
+        # param_groups as torch.optim.Optimizer.state_dict() lays them out: hyper-parameters + 'params' as running indices
+        start, groups = 0, []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(start, start + len(g["params"])))
+            start += len(g["params"])
+            groups.append(d)
+        split = [{"key": self._key_str(k), "parts": [k[0], str(k[1]), str(k[2]), str(k[3])], "pd": str(self._split_pd.get(k))}
+                 for k in self._split]
+        return {"psgdk_version": 2, "state": {},      # per-parameter state lives in the bucket arenas below
+                "param_groups": groups, "split": split,
                 "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
 
     def load_state_dict(self, sd):
         """Restores a state_dict() taken from an optimizer over the SAME parameters (same order, shapes, dtypes, sharding).
-        Buckets are built lazily, so this may be called right after construction; the arenas are filled at the first step."""
-        assert sd.get("psgdk_version") == 1, "not a psgd_torch_amd.KWNS4 state dict"
+        Buckets are built lazily, so this may be called right after construction; the arenas are filled when a bucket is first
+        used.  Buckets that had been split into per-parameter engines (parameters without gradients on some steps) come back
+        split."""
+        assert sd.get("psgdk_version") == 2, "not a psgd_torch_amd.KWNS4 state dict (version 2)"
         for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update(saved)
+            assert len(saved["params"]) == len(g["params"]), "checkpoint does not match this optimizer"
+            g.update({k: v for k, v in saved.items() if k != "params"})
         self._global_step = sd["global_step"]
         self._seed = sd["seed"]
         self._gate_gen.set_state(sd["gate_rng"])
-        self._pending_restore = list(sd["buckets"])
-        for b, saved in zip(self._buckets.values(), self._pending_restore):
-            self._restore_bucket(b, saved)
-        if self._buckets:
-            self._pending_restore = []
+
+        def _dt(s):
+            return None if s == "None" else getattr(torch, s.split(".")[-1])
+        for e in sd.get("split", []):
+            gi, pdt, gdt, dev = e["parts"]
+            key = (int(gi), _dt(pdt), _dt(gdt), torch.device(dev))
+            if key not in self._split:
+                if key in self._buckets:      # a batched bucket already exists here: drop it, its state comes from the checkpoint
+                    del self._buckets[key]
+                self._split.add(key)
+                self._split_pd[key] = _dt(e["pd"])
+        self._pending_restore = dict(sd["buckets"])
+        for key, b in self._buckets.items():
+            ks = self._key_str(key)
+            if ks in self._pending_restore:
+                self._restore_bucket(b, self._pending_restore.pop(ks))
 
     def _restore_bucket(self, b, saved):
         assert saved["n_params"] == len(b.params) and saved["owned"] == list(b.owned), "checkpoint does not match this optimizer"

@@ -45,21 +45,38 @@ class KWNS4(_base.KWNS4):
     def _has_work(self, p):
         return p.grad is not None and self._grad_of(p).numel() > 0                # ..._dtensor.py:114-115, 124-125
 
+    @staticmethod
+    def _bcast(view, src, pg):
+        # engine views are strided windows of the state arena (padded rows, transposed storage): broadcast a packed copy
+        t = view if view.is_contiguous() else view.contiguous()
+        torch.distributed.broadcast(t, src=src, group=pg)
+        if t is not view:
+            view.copy_(t)
+
     def _resync(self, b, plist):
-        # ..._dtensor.py:168-179: broadcast the replicated state inside every Replicate sub-group of the parameter's mesh.
-        # The engine state of a bucket is one arena; tensors of one bucket share a mesh in practice, so the arena follows
-        # the first DTensor's Replicate groups (parameters are broadcast individually).
-        groups = []
+        # ..._dtensor.py:168-179: inside every Replicate sub-group of a parameter's mesh, broadcast the parameter, its ema and
+        # every (Q, L) of it from the group's first rank.  Per PARAMETER, like the reference: ranks of one mesh hold different
+        # sets of non-empty local shards, so the buckets (and their arenas) of two ranks need not have the same composition --
+        # only the state of a replicated parameter is the same object on every rank of its Replicate group.
+        touched = False
         for p in plist:
             if not isinstance(p, DTensor):
                 continue
+            eng_k = self.state[p].get("exprs") if p in self.state else None
             for mesh_dim, placement in enumerate(p.placements):
-                if isinstance(placement, Replicate):
-                    pg = p.device_mesh.get_group(mesh_dim)
-                    src = torch.distributed.get_process_group_ranks(pg)[0]
-                    torch.distributed.broadcast(p.to_local(), src=src, group=pg)
-                    if not groups or all(g[0] is not pg for g in groups):
-                        groups.append((pg, src))
-        if b.engine is not None:
-            for pg, src in groups[:1]:
-                torch.distributed.broadcast(b.engine.state_arena, src=src, group=pg)
+                if not isinstance(placement, Replicate):
+                    continue
+                pg = p.device_mesh.get_group(mesh_dim)
+                src = torch.distributed.get_process_group_ranks(pg)[0]
+                torch.distributed.broadcast(p.to_local(), src=src, group=pg)
+                if eng_k is None:
+                    continue
+                eng, k = eng_k
+                if eng.use_momentum:
+                    self._bcast(eng.ema[k], src, pg)
+                for q, ell in zip(*eng.QL(k)):
+                    self._bcast(q, src, pg)
+                    self._bcast(ell, src, pg)
+                touched = True
+        if touched and b.engine is not None:
+            b.engine.state_changed()      # Q^T and the cached P = Q^T Q follow the received factors

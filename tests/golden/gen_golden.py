@@ -358,6 +358,14 @@ def gen_kron_geoms():
         gen_kron_geom_case(geom, "m64x64", (64, 64), all3, T=4, seed=b + 4, force_balance_at=2)
         gen_kron_geom_case(geom, "m150x200", (150, 200), ("fp32", "bf16"), T=2, seed=b + 5)
         gen_kron_geom_case(geom, "t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=b + 6)
+    # QUAD4P (psgd.py:486-513) fits P itself: own recipe (Scale 0.8 so that P = Q starts away from the identity)
+    kw = dict(Scale=0.8)
+    gen_kron_geom_case("QUAD4P", "vec33", (33,), all3, T=4, seed=111, **kw)
+    gen_kron_geom_case("QUAD4P", "m48x32", (48, 32), all3, T=6, seed=112, **kw)
+    gen_kron_geom_case("QUAD4P", "m32x48", (32, 48), all3, T=5, seed=113, **kw)
+    gen_kron_geom_case("QUAD4P", "m64x64", (64, 64), all3, T=4, seed=114, force_balance_at=2, **kw)
+    gen_kron_geom_case("QUAD4P", "m150x200", (150, 200), ("fp32", "bf16"), T=2, seed=115, **kw)
+    gen_kron_geom_case("QUAD4P", "t7x5x3", (7, 5, 3), ("fp64", "fp32"), T=3, seed=116, **kw)
 
 
 def gen_kron_pro4p_case(name, shape, dtypes, T, max_skew=1.0, max_size=float("inf"), Scale=0.8, lr=0.3, betaL=0.9,

@@ -44,7 +44,25 @@ class OracleEngine:
         self.ema = [torch.zeros(s, dtype=precond_dtype) if use_momentum else None for s in self.shapes]
         self.gc = [None] * self.n
         self.h = [None] * self.n
-        self.state_arena = torch.zeros(1)
+        # like the real engine, all persistent state (Q, L, ema) lives in ONE byte arena that the tensors above are views of,
+        # so that checkpoint / resync code paths that copy or broadcast `state_arena` are exercised on CPU as well
+        def nbytes(t):
+            return (t.numel() * t.element_size() + 15) // 16 * 16
+        tensors = [t for ql in self.QLs for part in ql for t in part] + [e for e in self.ema if e is not None]
+        self.state_arena = torch.zeros(max(sum(nbytes(t) for t in tensors), 16), dtype=torch.uint8)
+        off = 0
+
+        def rehome(t):
+            nonlocal off
+            v = self.state_arena[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+            v.copy_(t)
+            off += nbytes(t)
+            return v
+        for ql in self.QLs:
+            for part in ql:
+                for i in range(len(part)):
+                    part[i] = rehome(part[i])
+        self.ema = [rehome(e) if e is not None else None for e in self.ema]
 
     def QL(self, k):
         return self.QLs[k]

@@ -114,6 +114,52 @@ def test_no_cpu_fallback():
             opt.step()
 
 
+def test_engine_refuses_tensors_it_would_misread():
+    """The library walks raw pointers in logical-contiguous order with one element type per call: strided views, other
+    devices, mixed dtypes and wrong sizes must raise instead of corrupting (the reference's p.subtract_(h.view_as(p)) is
+    stride-safe, wrapped_as_torch_optimizer_for_ddp.py:157)."""
+    from psgd_torch_amd.engine import _check_tensors
+    from psgd_torch_amd._lib import PsgdkError
+    dev = torch.device("cpu")
+    ok = [torch.zeros(4, 6), torch.zeros(5)]
+    assert _check_tensors("params", ok, [24, 5], dev) == torch.float32
+    cl = torch.zeros(2, 3, 4, 4).to(memory_format=torch.channels_last)
+    for bad, numels in (([torch.zeros(6, 4).t(), ok[1]], [24, 5]),                       # transposed view
+                        ([cl], [96]),                                                    # channels_last conv weight
+                        ([ok[0], torch.zeros(5, dtype=torch.bfloat16)], [24, 5]),        # mixed dtypes in one call
+                        ([ok[0], torch.zeros(6)], [24, 5]),                              # wrong size
+                        ([ok[0]], [24, 5]),                                              # wrong count
+                        ([torch.zeros(4, 6, dtype=torch.float16)], [24])):               # unsupported element type
+        with pytest.raises(PsgdkError):
+            _check_tensors("params", bad, numels, dev)
+    with pytest.raises(PsgdkError):
+        _check_tensors("params", ok, [24, 5], torch.device("meta"))
+
+
+def test_replicated_resync_refreshes_engine_caches():
+    """KWNS4._resync (wrapped_as_torch_optimizer_for_ddp.py:163-170) must tell the engine that the factors changed under it
+    (the cached P = Q^T Q lives outside the broadcast arena)."""
+    import psgd_torch_amd
+    from psgd_torch_amd.kwns4 import _Bucket
+    calls = []
+
+    class Eng:
+        state_arena = torch.zeros(4)
+
+        def state_changed(self):
+            calls.append("changed")
+    b = _Bucket()
+    b.engine = Eng()
+    opt = psgd_torch_amd.KWNS4([torch.nn.Parameter(torch.zeros(4, 4))])
+    orig = torch.distributed.broadcast
+    torch.distributed.broadcast = lambda t, src=0, group=None: None
+    try:
+        opt._resync(b, [torch.zeros(3)])
+    finally:
+        torch.distributed.broadcast = orig
+    assert calls == ["changed"]
+
+
 def test_kwns4_surface_matches_reference():
     """Same kwargs, defaults and assertion sites as wrapped_as_torch_optimizer_for_ddp.py:25-62."""
     import inspect

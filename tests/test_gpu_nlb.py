@@ -1,0 +1,112 @@
+"""
+The cooperative spectral-norm bound (nlb_coop_kernel: norm_lower_bound_spd/_skh, psgd.py:46-93, in ONE launch per bound with the
+S workgroups of a factor exchanging their slabs inside the launch) under conditions that break a placement- or timing-dependent
+exchange: thousands of launches while a second stream keeps every CU busy with unrelated work (siblings start at different
+times, on whatever CUs free up), L1-warm consumers (the same buffers are re-read launch after launch), every word checked
+against the multi-launch route of the same arithmetic.  Plus the failure path: a sibling that never arrives must surface as
+PSGDK_ERR_NLB_TIMEOUT / a warning, leave the state valid and move the plan to the multi-launch route.
+"""
+import ctypes as C
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _engine(n_factors, width, dt):
+    import psgd_torch_amd as amd
+    from psgd_torch_amd import _lib as L
+    # (4*width, width): the long dim is diagonal (max_skew 1), the short one a dense factor -- GPT-2-small's c_fc shape at 768
+    eng = amd.KronEngine([(4 * width, width)] * n_factors, DEV, precond_dtype=dt, use_momentum=False, init_scale=1.0)
+    g = torch.Generator().manual_seed(1)
+    grads = [(0.3 * torch.randn(4 * width, width, generator=g)).to(dt).to(DEV) for _ in range(n_factors)]
+    eng.accumulate(grads, keep_grad=True)
+    eng.update_precond(L.SRC_GRAD, 0.5, 0.9, 1e-9, seed=3, offset=0, balance_mask=[False] * n_factors)   # fills term1, R, row stats
+    torch.cuda.synchronize()
+    return eng, grads
+
+
+def _run_bound(eng, chain, route, seed, vsq, v, fault=0):
+    from psgd_torch_amd import _lib as L
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(eng.lib.psgdk_test_nlb(eng._plan, chain, route, seed, 0, vsq.data_ptr(), v.data_ptr(), fault, st), "test_nlb")
+
+
+@pytest.mark.parametrize("dt,width,n_factors,iters", [(torch.bfloat16, 768, 62, 1000), (torch.float32, 384, 40, 300),
+                                                       (torch.bfloat16, 320, 24, 300)])
+def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
+    """GPT-2-small's plan (62 factors x 768, S = 3) and two other widths: 2 chains x iters bounds, a saturating side stream,
+    each launch compared with the multi-launch route on the same inputs and noise.  The two routes share MFMA, K order and
+    rounding points; they differ only through the order of the fp32 row-sum atomics, i.e. by ~1 ulp of fp32 in the row scales,
+    which can flip the rounding of an element of V: bounded by a few ulp of the element type on V, 1e-5 on the sums."""
+    eng, _ = _engine(n_factors, width, dt)
+    info = eng.info()
+    assert info["nlb_coop"] == 1, info
+    F, dp = info["dense_factors"], info["max_dense_dim"]
+    vsq_ref = torch.zeros(F, 4, 32, device=DEV)
+    v_ref = torch.zeros(F, 32, dp, device=DEV, dtype=dt)
+    vsq = torch.zeros_like(vsq_ref)
+    v = torch.zeros_like(v_ref)
+    # unrelated work on a second stream: large matmuls that keep all CUs occupied and make the siblings' start times uneven
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    stop = {"n": 0}
+    worst_v = torch.zeros((), device=DEV)
+    worst_s = torch.zeros((), device=DEV)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -22
+    for chain in (0, 1):
+        for it in range(iters):
+            if it % 4 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        a = (a @ a).clamp_(-1, 1)
+                    stop["n"] += 1
+            seed = 1000 * chain + it // 2          # every noise draw is used twice: the second launch re-reads warm lines
+            _run_bound(eng, chain, 0, seed, vsq_ref, v_ref)
+            _run_bound(eng, chain, 1, seed, vsq, v)
+            dv = (v.float() - v_ref.float()).abs().amax() / v_ref.float().abs().amax().clamp_min(1e-30)
+            ds = ((vsq - vsq_ref).abs() / vsq_ref.abs().clamp_min(1e-30)).amax()
+            worst_v = torch.maximum(worst_v, dv)
+            worst_s = torch.maximum(worst_s, ds)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(v_ref.float()).all()) and float(v_ref.float().abs().max()) > 0
+    assert float(worst_s) <= 1e-5, float(worst_s)
+    assert float(worst_v) <= 4 * ulp, (float(worst_v), ulp)
+    assert eng.info()["nlb_fallbacks"] == 0 and eng.info()["nlb_coop"] == 1
+
+
+def test_cooperative_bound_timeout_is_reported_and_falls_back():
+    """A sibling that never announces its slab: the waiting workgroups give up after the spin limit, the factor's step is
+    skipped (mu = 0 / s = 0: state stays finite), the host-mapped error word is set, the next update call returns
+    PSGDK_ERR_NLB_TIMEOUT exactly once -- the engine warns and repeats the call on the multi-launch route."""
+    from psgd_torch_amd import _lib as L
+    eng, grads = _engine(8, 768, torch.bfloat16)
+    assert eng.info()["nlb_coop"] == 1
+    F, dp = eng.info()["dense_factors"], eng.info()["max_dense_dim"]
+    vsq = torch.zeros(F, 4, 32, device=DEV)
+    v = torch.zeros(F, 32, dp, device=DEV, dtype=torch.bfloat16)
+    _run_bound(eng, 0, 1, 5, vsq, v, fault=1)
+    torch.cuda.synchronize()          # (the word is written by the kernel; the library itself never synchronises for it)
+    q_before = [q.clone() for q in eng.Q[0]]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.accumulate(grads, keep_grad=True)
+        eng.update_precond(L.SRC_GRAD, 0.5, 0.9, 1e-9, seed=4, offset=0, balance_mask=[False] * 8)
+    assert any("timed out" in str(x.message) for x in w), [str(x.message) for x in w]
+    info = eng.info()
+    assert info["nlb_coop"] == 0 and info["nlb_fallbacks"] == 1, info
+    torch.cuda.synchronize()
+    for t in range(8):
+        for q in eng.Q[t]:
+            assert bool(torch.isfinite(q.float()).all())
+    assert any(not torch.equal(a, b) for a, b in zip(q_before, eng.Q[0])), "the repeated call must have updated Q"
+    # and the next call is silent
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        eng.accumulate(grads, keep_grad=True)
+        eng.update_precond(L.SRC_GRAD, 0.5, 0.9, 1e-9, seed=5, offset=0, balance_mask=[False] * 8)
+    assert not w2

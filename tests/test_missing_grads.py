@@ -56,3 +56,38 @@ def test_missing_gradients_follow_the_reference_loop():
         assert opt.state[a]["step"] == steps[i] == ref.state[i]["step"]
         for qa, qb in zip(opt.state[a]["QL"][0], ref.state[i]["QL"][0]):
             assert torch.equal(qa, qb)
+
+
+def test_checkpoint_round_trip_after_a_bucket_split():
+    """state_dict()/load_state_dict() once the batched bucket has been split into per-parameter engines (the set of
+    parameters with gradients changed): N steps + save + M steps == fresh optimizer, load, M steps -- bit for bit -- and the
+    saved param_groups carry 'params' index lists like any torch optimizer's."""
+    import copy
+    import psgd_torch_amd
+    kw = dict(preconditioner_dtype=torch.float32, lr_params=1e-2, lr_preconditioner=0.3, momentum=0.9, weight_decay=0.01)
+    pa = _params(3)
+    oa = psgd_torch_amd.KWNS4(pa, engine_factory=OracleEngine, seed=5, **kw)
+    gg = torch.Generator().manual_seed(99)
+    stream = [[0.3 * torch.randn(s, generator=gg) for s in SHAPES] for _ in range(len(PATTERN) + 3)]
+
+    def run(opt, params, lo, hi):
+        for t in range(lo, hi):
+            missing = PATTERN[t] if t < len(PATTERN) else set()
+            for i, p in enumerate(params):
+                p.grad = None if i in missing else stream[t][i].clone()
+            opt.step()
+    run(oa, pa, 0, 4)                       # the split happens at step 1
+    assert oa._split
+    sd = copy.deepcopy(oa.state_dict())
+    assert sd["param_groups"][0]["params"] == list(range(len(SHAPES)))
+    snap = [p.detach().clone() for p in pa]
+    run(oa, pa, 4, len(stream))
+    pb = [torch.nn.Parameter(x.clone()) for x in snap]
+    ob = psgd_torch_amd.KWNS4(pb, engine_factory=OracleEngine, seed=123, **kw)      # (the seed comes from the checkpoint)
+    ob.load_state_dict(sd)
+    run(ob, pb, 4, len(stream))
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a.data, b.data), f"parameter {i} differs after resume"
+        assert oa.state[a]["step"] == ob.state[b]["step"]
+        for qa, qb in zip(oa.state[a]["QL"][0], ob.state[b]["QL"][0]):
+            assert torch.equal(qa, qb)
