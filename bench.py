@@ -9,10 +9,14 @@ ranks (shard_state=True; the clipped preconditioned gradients are exchanged with
 --parallelism auto (default) times both in warm-up and keeps the faster; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
-  roofline     -- for the dominant kernel (the grouped NT MFMA GEMM, both tilings): algorithmic FLOPs of a step (SURVEY 8d
-                  model, 905.2 GFLOP, all of it in the 17 GEMM launches) / their launch time measured live with hipEvents
-                  on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
-  cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on a bounded sample.
+  roofline     -- for the dominant kernel (the grouped NT MFMA GEMM, both tilings): the algorithmic FLOPs of a step that run in
+                  it (SURVEY 8d model: 905.2 GFLOP per step, minus the 2 x 256 d^2 of the two norm bounds when the cooperative
+                  kernel runs them = 886.5 GFLOP in 9 launches) / their launch time measured live with hipEvents on the launch
+                  stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on a bounded sample: ONE of the
+                  12 transformer blocks, at all host threads and at 8 threads; the whole-model figure is an extrapolation.
+After the timed region every parameter and the whole preconditioner state are checked to be finite (a fast wrong step is not
+a measurement).
 """
 import argparse
 import json
@@ -55,28 +59,57 @@ def flop_model(shapes, max_skew=1.0, nlb_in_gemm=True):
     return step, gemm
 
 
-def cpu_baseline(seconds_budget=12.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(seconds_budget=9.0):
     """The CPU oracle (oracle/psgd_oracle.py, a port of the reference path) on ONE GPT-2-small transformer block
-    (12 tensors, 7,087,872 params), bf16 preconditioner, same hyper-parameters; bounded to ~seconds_budget."""
+    (12 tensors, 7,087,872 params = 1/17.6 of the model; 58 of the step's 905 GFLOP), bf16 preconditioner, same
+    hyper-parameters, at two thread counts: every host thread torch will use, and 8 (comparable with the survey
+    container's probe of the reference itself, BASELINE.md section 2: 0.23-0.28 s per block).  Bounded to ~2 x seconds_budget.
+    `value` is the block's own rate at all threads; the whole-model step is an extrapolation (wte alone is another ~20 %)."""
     from oracle import psgd_oracle as orc
     shapes = gpt2_shapes()[2:14]
-    gen = torch.Generator().manual_seed(0)
-    params = [0.02 * torch.randn(*s, generator=gen) for s in shapes]
-    opt = orc.KWNS4Oracle(params, seed=0)
-    nparam = sum(p.numel() for p in params)
-    times = []
-    t_all = time.time()
-    for it in range(50):
-        grads = [0.01 * torch.randn(*s, generator=gen) for s in shapes]
-        t0 = time.time()
-        opt.step(grads)
-        times.append(time.time() - t0)
-        if it >= 2 and time.time() - t_all > seconds_budget:
-            break
-    steady = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": nparam / steady / 1e9, "unit": "Gparam/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 of 12 GPT-2-small blocks (12 tensors, {nparam} params), bf16 preconditioner, "
-                      f"median of {len(times) - 1} steps, {steady * 1e3:.0f} ms/step"}
+    nparam = sum(math.prod(s) for s in shapes)
+    n_all = torch.get_num_threads()
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        gen = torch.Generator().manual_seed(0)
+        params = [0.02 * torch.randn(*s, generator=gen) for s in shapes]
+        opt = orc.KWNS4Oracle(params, seed=0)
+        times = []
+        t_all = time.time()
+        for it in range(50):
+            grads = [0.01 * torch.randn(*s, generator=gen) for s in shapes]
+            t0 = time.time()
+            opt.step(grads)
+            times.append(time.time() - t0)
+            if it >= 2 and time.time() - t_all > seconds_budget:
+                break
+        return sorted(times[1:])[len(times[1:]) // 2], len(times) - 1
+    try:
+        s_all, k_all = run(n_all)
+        s_8, k_8 = run(min(8, n_all))
+    finally:
+        torch.set_num_threads(n_all)
+    full_step_flops, _ = flop_model(gpt2_shapes())
+    block_flops, _ = flop_model(shapes)
+    return {"value": nparam / s_all / 1e9, "unit": "Gparam/s", "cores": n_all, "kind": "port", "cpu_model": _cpu_model(),
+            "ms_per_block_step": s_all * 1e3, "gflops": block_flops / s_all / 1e9,
+            "threads8": {"value": nparam / s_8 / 1e9, "ms_per_block_step": s_8 * 1e3, "gflops": block_flops / s_8 / 1e9, "cores": min(8, n_all)},
+            "extrapolated_full_step_s": {"all_threads": s_all * full_step_flops / block_flops, "threads8": s_8 * full_step_flops / block_flops},
+            "sample": f"ONE of 12 GPT-2-small transformer blocks (12 tensors, {nparam} params, {block_flops / 1e9:.0f} of the step's "
+                      f"{full_step_flops / 1e9:.0f} GFLOP), bf16 preconditioner; median of {k_all} steps at {n_all} threads "
+                      f"({s_all * 1e3:.0f} ms) and of {k_8} steps at 8 threads ({s_8 * 1e3:.0f} ms); whole-model figures are "
+                      "extrapolated by the FLOP model, not measured; baseline only"}
 
 
 def bench_lra(args):
@@ -292,6 +325,23 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # a fast wrong step is not a measurement: every parameter and the whole preconditioner state (Q, Q^T, diagonal factors,
+    # L, momentum: one arena per engine) must be finite after the timed region
+    bad = [i for i, p in enumerate(params) if not bool(torch.isfinite(p).all())]
+    for e in engines:
+        for t in range(e.n):
+            for q in e.Q[t]:
+                if not bool(torch.isfinite(q.float()).all()):
+                    bad.append(("Q", t))
+            for ell in e.Lip[t]:
+                if not bool(torch.isfinite(ell).all()):
+                    bad.append(("L", t))
+            if e.ema[t] is not None and not bool(torch.isfinite(e.ema[t].float()).all()):
+                bad.append(("ema", t))
+    if bad:
+        raise SystemExit(f"bench.py: non-finite values after the timed region: {bad[:8]}")
+    nlb_fallbacks = sum(e.info()["nlb_fallbacks"] for e in engines)
+
     # secondary figure: the apply-only step, i.e. the steady state once the update probability is annealed down
     # (momentum + precondition + clip + parameter update; the preconditioner update gated off).  Outside the timed region.
     apply_only_ms = None
@@ -336,7 +386,8 @@ def main():
                    "parallelism_probe_ms": ({k: v * 1e3 for k, v in timing.items()} if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                    "apply_only_ms_per_step": apply_only_ms,
-                   "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products"},
+                   "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products",
+                   "norm_bound_timeouts": nlb_fallbacks, "state_finite_after_timed_region": True},
     }
     if world == 1 and gemm_launches and prof_steps:
         launches_per_step = gemm_launches / prof_steps

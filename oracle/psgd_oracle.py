@@ -607,6 +607,84 @@ class KWNS4Oracle:
                                                      lr=g["lr_preconditioner"], betaL=g["betaL"], damping=g["damping"])
 
 
+class KronWhitenOracle:
+    """psgd.py:516-654 (KronWhiten) restated with explicit gradients instead of a closure, for dQ in {"Q0.5EQ1.5", "QUAD4P"}.
+    `uniform()` supplies the per-step gate (psgd.py:615) and `noise_for(G, kinds)` the KronNoise of each update call, in the
+    reference's order: ALL tensors are updated, then ALL are preconditioned (psgd.py:620-639), then clipped and applied per
+    tensor (psgd.py:642-651).  The attributes the reference lets users anneal are plain members here too."""
+
+    def __init__(self, params: List[Tensor], preconditioner_max_size=float("inf"), preconditioner_max_skew=1.0,
+                 preconditioner_init_scale: Optional[float] = None, lr_params=0.001, lr_preconditioner=0.1, betaL=0.9,
+                 damping=1e-9, momentum=0.0, grad_clip_max_amps=(2.0, 10.0), preconditioner_update_probability=1.0,
+                 update_preconditioner_first=True, whiten_grad=True, dQ="Q0.5EQ1.5",
+                 uniform: Optional[Callable[[], float]] = None,
+                 noise_for: Optional[Callable[[Tensor, Sequence[str]], KronNoise]] = None, seed: int = 0):
+        assert dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5", "QUAD4P")
+        self.params = params
+        self.lr_params, self.lr_preconditioner, self.betaL, self.damping = lr_params, lr_preconditioner, betaL, damping
+        self.momentum = momentum if (0 < momentum < 1) else 0.0                                       # psgd.py:545
+        self.grad_clip_max_amps = grad_clip_max_amps
+        self.preconditioner_update_probability = preconditioner_update_probability
+        self.update_preconditioner_first = update_preconditioner_first
+        self._max_size, self._max_skew, self._dQ = preconditioner_max_size, preconditioner_max_skew, dQ
+        self._p4 = dQ == "QUAD4P"
+        self.QLs, self.kinds = None, None
+        if preconditioner_init_scale is not None:                                                     # psgd.py:558
+            self._init([p.squeeze() for p in params], preconditioner_init_scale)
+        self.ms, self._counter_m = None, 0
+        self._whiten_grad = whiten_grad
+        if not whiten_grad:
+            assert self.momentum > 0
+        gen = torch.Generator().manual_seed(seed)
+        self._uniform = uniform if uniform is not None else (lambda: float(torch.rand([], generator=gen)))
+        self._noise_for = noise_for if noise_for is not None else (lambda G, kinds: KronNoise.draw(G, kinds, gen))
+
+    def _init(self, like: List[Tensor], scale):
+        s = scale ** 2 if self._p4 else scale                                                         # psgd.py:186-187
+        both = [init_kron(t, Scale=s, max_size=self._max_size, max_skew=self._max_skew) for t in like]
+        self.QLs, self.kinds = [b[0] for b in both], [b[1] for b in both]
+
+    @torch.no_grad()
+    def step(self, grads: List[Tensor]) -> None:
+        grads = [g.squeeze() for g in grads]                                                          # psgd.py:597
+        if self.QLs is None:                                                                          # psgd.py:599-602
+            scale = max([torch.mean((torch.abs(g)) ** 4) for g in grads])
+            scale = (scale + self.damping ** 4) ** (-1 / 8)
+            self._init(grads, scale)
+        if self.momentum > 0:                                                                         # psgd.py:604-613
+            beta = min(self._counter_m / (1 + self._counter_m), self.momentum)
+            self._counter_m += 1
+            if self.ms is None:
+                self.ms = [torch.zeros_like(g) for g in grads]
+            for m, g in zip(self.ms, grads):
+                m.mul_(beta).add_(g, alpha=1 - beta)
+        else:
+            self.ms, self._counter_m = None, 0
+        if self._uniform() < self.preconditioner_update_probability:                                  # psgd.py:615-618
+            first, last = self.update_preconditioner_first, not self.update_preconditioner_first
+        else:
+            first, last = False, False
+        upd = update_precond_kron_whiten_quad4p if self._p4 else update_precond_kron_whiten_q0p5eq1p5
+        apply_ = (lambda Q, G: apply_q_kron(Q, G)) if self._p4 else precond_grad_kron                 # psgd.py:573 / 575
+
+        def update_all():
+            for QL, kinds, x in zip(self.QLs, self.kinds, grads if self._whiten_grad else self.ms):
+                upd(QL, x, self._noise_for(x, kinds), lr=self.lr_preconditioner, betaL=self.betaL, damping=self.damping)
+        if first:
+            update_all()                                                                              # psgd.py:620-626
+        src = self.ms if self.momentum > 0 else grads                                                 # psgd.py:628-631
+        pre = [apply_(QL[0], x) for QL, x in zip(self.QLs, src)]
+        if last:
+            update_all()                                                                              # psgd.py:633-639
+        max_avg_amp, max_element_amp = self.grad_clip_max_amps                                        # psgd.py:642-651
+        for p, h in zip(self.params, pre):
+            avg_amp = torch.sqrt(torch.mean(h * h))
+            if avg_amp > max_avg_amp:
+                h = h * (max_avg_amp / avg_amp)
+            h = h.clamp(min=-max_element_amp, max=max_element_amp)
+            p.subtract_(h.view_as(p), alpha=self.lr_params)
+
+
 class LRAWhitenOracle:
     """psgd.py:1075-1190 restated with explicit gradients instead of a closure (the closure/autograd front end
     is out of scope); U/V initial values and every random draw are supplied by the caller."""

@@ -42,7 +42,7 @@ class KronWhiten:
         self._init_scale = preconditioner_init_scale
         if preconditioner_init_scale is None:
             print("FYI: Will set the preconditioner initial scale on the fly. Recommend to set it manually.")
-        self._engine: Optional[KronEngine] = None
+        self._engines = None          # [(KronEngine, [indices into _params_with_grad])]: one engine per (param dtype, grad dtype)
         self._counter_m = 0
         self._step = 0
         self._whiten_grad = whiten_grad
@@ -50,17 +50,32 @@ class KronWhiten:
             assert self.momentum > 0, "Cannot whiten momentum if the momentum setting is invalid."
         self._seed = int(seed)
         self._gate_gen = torch.Generator().manual_seed(self._seed)
+        self._replay = None           # tests: callable(indices) -> dict(noise=..., balance_mask=...) feeding recorded draws
 
     def _uniform(self) -> float:
         return float(torch.rand([], generator=self._gate_gen))
 
-    def _make_engine(self, grads, scale):
-        p0 = self._params_with_grad[0]
-        self._engine = KronEngine([tuple(g.shape) for g in grads], p0.device, precond_dtype=grads[0].dtype,
-                                  max_size=self._preconditioner_max_size, max_skew=self._preconditioner_max_skew,
-                                  use_momentum=True, init_scale=float(scale) ** (2 if self._dQ in ("QUAD4P", "PRO4P") else 1),
-                                  geometry=self._dQ)
-        self._QLs = [self._engine.QL(k) for k in range(len(grads))]
+    @property
+    def _engine(self) -> Optional[KronEngine]:
+        """The engine of the first (usually only) dtype bucket."""
+        return self._engines[0][0] if self._engines else None
+
+    def _make_engines(self, grads, scale):
+        # one batched engine per (parameter dtype, gradient dtype): an engine call takes ONE element type for all its tensors
+        # (the reference initialises each tensor's factors in that tensor's own dtype, psgd.py:558,602)
+        groups = {}
+        for i, (p, g) in enumerate(zip(self._params_with_grad, grads)):
+            groups.setdefault((p.dtype, g.dtype, p.device), []).append(i)
+        self._engines = []
+        self._QLs = [None] * len(grads)
+        for (pdt, gdt, dev), idx in groups.items():
+            eng = KronEngine([tuple(grads[i].shape) for i in idx], dev, precond_dtype=gdt,
+                             max_size=self._preconditioner_max_size, max_skew=self._preconditioner_max_skew,
+                             use_momentum=True, init_scale=float(scale) ** (2 if self._dQ in ("QUAD4P", "PRO4P") else 1),
+                             geometry=self._dQ, tensor_ids=idx)
+            self._engines.append((eng, idx))
+            for k, i in enumerate(idx):
+                self._QLs[i] = eng.QL(k)
 
     @torch.no_grad()
     def step(self, closure):
@@ -68,21 +83,21 @@ class KronWhiten:
             closure_returns = closure()
             loss = closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
             grads = [g.squeeze().contiguous() for g in torch.autograd.grad(loss, self._params_with_grad)]   # psgd.py:594-597
-        if self._engine is None:
+        if self._engines is None:
             if self._init_scale is None:                                                                     # psgd.py:599-602
                 scale = max([torch.mean((torch.abs(g)) ** 4) for g in grads])
                 scale = float((scale + self.damping ** 4) ** (-1 / 8))
             else:
                 scale = self._init_scale
-            self._make_engine(grads, scale)
-        eng = self._engine
+            self._make_engines(grads, scale)
         if self.momentum > 0:                                                                                # psgd.py:604-613
             beta = min(self._counter_m / (1 + self._counter_m), self.momentum)
             self._counter_m += 1
         else:
             if self._counter_m:
-                for e in eng.ema:
-                    e.zero_()
+                for eng, _ in self._engines:
+                    for e in eng.ema:
+                        e.zero_()
             beta, self._counter_m = 0.0, 0
         if self._uniform() < self.preconditioner_update_probability:                                         # psgd.py:615-618
             first, last = self.update_preconditioner_first, not self.update_preconditioner_first
@@ -93,25 +108,32 @@ class KronWhiten:
         src_p = L.SRC_EMA if use_m else L.SRC_GRAD
         t = self._step
         damp = None
-        if (first or last) and self._dQ != "EQ":          # (the EQ update builds its own (V, Hvp) pair)
+        if (first or last) and self._dQ != "EQ" and self._replay is None:      # (the EQ update builds its own (V, Hvp) pair)
             damp = dict(source=src_w, damping=self.damping, seed=self._seed, offset=2 * t + (0 if first else 1))
-        if use_m:
-            eng.accumulate(grads, beta=beta, keep_grad=(src_w == L.SRC_GRAD), damp=damp)
-        else:
-            # no momentum: the EMA buffer is bypassed (beta = 0 would overwrite it with the gradient, which is harmless
-            # because a later switch to momentum > 0 restarts from counter 0 exactly like psgd.py:612-613)
-            eng.accumulate(grads, beta=0.0, keep_grad=True, damp=damp)
+        for eng, idx in self._engines:
+            g_ = [grads[i] for i in idx]
+            if use_m:
+                eng.accumulate(g_, beta=beta, keep_grad=(src_w == L.SRC_GRAD), damp=damp)
+            else:
+                # no momentum: the EMA buffer is bypassed (beta = 0 would overwrite it with the gradient, which is harmless
+                # because a later switch to momentum > 0 restarts from counter 0 exactly like psgd.py:612-613)
+                eng.accumulate(g_, beta=0.0, keep_grad=True, damp=damp)
 
-        def gates():
-            return [self._uniform() < 0.01 for _ in grads]
+        def update_all(offset):
+            # psgd.py:620-626 / 633-639: every tensor's update (with its own draws, in parameter order) before anything else
+            for eng, idx in self._engines:
+                if self._replay is not None:
+                    draws = self._replay(idx)
+                else:
+                    draws = dict(noise=None, balance_mask=[self._uniform() < 0.01 for _ in idx])
+                eng.update_precond(src_w, self.lr_preconditioner, self.betaL, self.damping, seed=self._seed, offset=offset, **draws)
         if first:
-            eng.update_precond(src_w, self.lr_preconditioner, self.betaL, self.damping, seed=self._seed, offset=2 * t,
-                               balance_mask=gates())
-        eng.precond_grad(src_p)
+            update_all(2 * t)
         max_avg_amp, max_element_amp = self.grad_clip_max_amps                                                # psgd.py:642-651
-        eng.apply_update(self._params_with_grad, self.lr_params, 0.0, max_avg_amp, max_element_amp)
+        for eng, idx in self._engines:
+            eng.precond_grad(src_p)
+            eng.apply_update([self._params_with_grad[i] for i in idx], self.lr_params, 0.0, max_avg_amp, max_element_amp)
         if last:
-            eng.update_precond(src_w, self.lr_preconditioner, self.betaL, self.damping, seed=self._seed, offset=2 * t + 1,
-                               balance_mask=gates())
+            update_all(2 * t + 1)
         self._step += 1
         return closure_returns

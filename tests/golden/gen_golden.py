@@ -515,6 +515,72 @@ def gen_kwns4():
 
 
 # ------------------------------------------------------------------------------------------------
+# C2. KronWhiten.step (psgd.py:589-654): the closure-style shell -- on-the-fly initial scale (:599-602), all updates then all
+#     applies (:620-639), per-tensor clipping (:642-651)
+# ------------------------------------------------------------------------------------------------
+KWH_SHAPES = [(24, 16), (16,), (3, 4, 5), (1, 12, 1), (20, 20), ()]
+
+
+def gen_kronwhiten_case(name, T=4, seed=0, grad_scale=1.0, force_gate=None, **kw):
+    out = {"T": np.asarray(T), "nparams": np.asarray(len(KWH_SHAPES))}
+    for k, v in kw.items():
+        if k == "grad_clip_max_amps":
+            out["kw_" + k] = np.asarray(v, dtype=np.float64)
+        elif k == "dQ":
+            out["kw_" + k] = np.asarray(v)
+        else:
+            out["kw_" + k] = np.asarray(v if v is not None else float("nan"))
+    g = torch.Generator().manual_seed(600 + seed)
+    params = [torch.nn.Parameter(0.5 * torch.randn(s, generator=g)) for s in KWH_SHAPES]
+    for i, p in enumerate(params):
+        out[f"p{i}_init"] = npy(p.data)
+        out[f"p{i}_shape"] = np.asarray(p.shape, dtype=np.int64)
+    opt = psgd.KronWhiten(params, **kw)
+    torch.manual_seed(950 + seed)
+    for t in range(T):
+        cs = []
+        for i, s in enumerate(KWH_SHAPES):
+            sq = tuple(d for d in s if d != 1)
+            G = structured_grads(sq, 1, seed * 1000 + 19 * t + i)[0].reshape(s) * (grad_scale / 0.3)
+            cs.append(G)
+            out[f"t{t}_g{i}"] = npy(G)
+
+        def closure():          # linear loss: its gradient is exactly cs, whatever the parameters are
+            return sum((p * c).sum() for p, c in zip(params, cs))
+
+        force = [force_gate[t]] if force_gate is not None else None
+        with Recorder(force_rand=force) as r:
+            opt.step(closure)
+        # recorded stream: the step's gate first (psgd.py:615), then -- if the step updates -- per tensor: randn_like(G),
+        # per dense factor its subspace draws (spd, and skh for Q0.5EQ1.5), rand([]) of the balancing
+        out[f"t{t}_ndraws"] = np.asarray(len(r.draws))
+        for k, (kind, x) in enumerate(r.draws):
+            out[f"t{t}_draw{k}"] = npy(x)
+            out[f"t{t}_draw{k}_kind"] = np.asarray(kind)
+        for i, p in enumerate(params):
+            out[f"t{t}_p{i}"] = npy(p.data)
+            if opt._ms is not None:
+                out[f"t{t}_m{i}"] = npy(opt._ms[i])
+            for j, (q, ell) in enumerate(zip(*opt._QLs_exprs[i][0])):
+                out[f"t{t}_p{i}_Q{j}"] = npy(q)
+                out[f"t{t}_p{i}_L{j}"] = npy(ell)
+    save("kronwhiten_" + name, out)
+
+
+def gen_kronwhiten():
+    gen_kronwhiten_case("momentum_onthefly", seed=1, momentum=0.9, whiten_grad=False, preconditioner_init_scale=None,
+                        lr_params=0.01, lr_preconditioner=0.3)
+    gen_kronwhiten_case("nomomentum_last_clip", seed=2, momentum=0.0, whiten_grad=True, preconditioner_init_scale=0.7,
+                        update_preconditioner_first=False, grad_scale=6.0, grad_clip_max_amps=(1.2, 2.0), lr_params=0.01,
+                        lr_preconditioner=0.5)
+    gen_kronwhiten_case("quad4p_momentum_whitengrad", seed=3, dQ="QUAD4P", momentum=0.9, whiten_grad=True,
+                        preconditioner_init_scale=None, lr_params=0.01, lr_preconditioner=0.2)
+    gen_kronwhiten_case("prob_skewinf", seed=4, T=6, preconditioner_update_probability=0.5, preconditioner_max_skew=float("inf"),
+                        preconditioner_init_scale=1.0, momentum=0.5, whiten_grad=False, lr_params=0.01, lr_preconditioner=0.3,
+                        force_gate=[0.1, 0.9, 0.2, 0.8, 0.3, 0.7])
+
+
+# ------------------------------------------------------------------------------------------------
 # D. LRA functional + LRAWhiten.step
 # ------------------------------------------------------------------------------------------------
 def gen_lra_case(name, N, r, dtypes, T=4, lr=0.1, betaL=0.9, damping=1e-9, seed=0, prefix="lra_"):
@@ -605,4 +671,5 @@ if __name__ == "__main__":
     gen_kron_geoms()
     gen_kron_pro4p()
     gen_kwns4()
+    gen_kronwhiten()
     gen_lra()

@@ -44,7 +44,9 @@ def _worker(rank, world, port, outdir, pd):
         import psgd_torch_amd
         from psgd_torch_amd.kwns4_dtensor import KWNS4 as DKWNS4
         dev = "cuda:0"
-        mesh = init_device_mesh("cuda", (world,))
+        # (gloo for the mesh's own group too: torch would otherwise pair cuda tensors with an RCCL group, which refuses two
+        #  ranks on one device)
+        mesh = init_device_mesh("cuda", (world,), backend_override={0: "gloo"})
         pl = {"shard": [Shard(0)], "replicate": [Replicate()]}
 
         def dt_of(full, kind):

@@ -81,7 +81,7 @@ def test_eq_functional_seam_vs_golden(name):
                 if dn == "fp32":
                     assert relerr(got, gold) <= 3e-5 * (t + 1), (name, dn, t, what, relerr(got, gold))
                 else:
-                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    floor = 2 * 7.8125e-3 if what.startswith("L") else 7.8125e-3      # 2 / 1 bf16 ulp; observed e_hip ~ e_ref (profiles/r01_l_parity_report.md)
                     e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
@@ -201,7 +201,7 @@ def test_qeq_quad_functional_seam_vs_golden(name):
                 if dn == "fp32":
                     assert relerr(got, gold) <= 3e-5 * (t + 1), (name, dn, t, what, relerr(got, gold))
                 else:
-                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    floor = 2 * 7.8125e-3 if what.startswith("L") else 7.8125e-3      # 2 / 1 bf16 ulp; observed e_hip ~ e_ref (profiles/r01_l_parity_report.md)
                     e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
@@ -269,6 +269,6 @@ def test_pro4p_functional_seam_vs_golden(name):
                 if dn == "fp32":
                     assert relerr(got, gold) <= 1e-3, (name, dn, t, what, relerr(got, gold))
                 else:
-                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    floor = 2 * 7.8125e-3 if what.startswith("L") else 7.8125e-3      # 2 / 1 bf16 ulp; observed e_hip ~ e_ref (profiles/r01_l_parity_report.md)
                     e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)

@@ -6,9 +6,9 @@ Tolerances (relative Frobenius, identical replayed noise):
   fp32: <= 3e-5 per step vs the reference's own fp32 output (golden) for P = Q^T Q, L, h (Q itself is gauge-dependent,
         SURVEY H1, and is checked through P);
   bf16: error vs the fp64 ORACLE trajectory on the same inputs must be <= 1.5x the reference-bf16's own error vs that
-        trajectory, plus a floor of 2 bf16 ulp (2e-2; 4e-2 for L which goes with the 4th power of the bf16 state) --
-        the HIP path accumulates in fp32 and rounds less often than the bf16 reference, so it may differ from the bf16
-        golden by as much as the golden differs from truth.
+        trajectory, plus a floor of 1 bf16 ulp (7.8e-3; 2 ulp for L) for the first steps, where the reference's own error
+        is still ~0 -- the HIP path accumulates in fp32 and rounds less often than the bf16 reference, so it may differ
+        from the bf16 golden by as much as the golden differs from truth (observed: 0.7 .. 1.1 x the reference's error).
 """
 import ctypes as C
 
@@ -127,9 +127,10 @@ def test_functional_seam_vs_golden(name):
                 if dn == "fp32":
                     assert relerr(got, gold) <= 3e-5 * (t + 1), (name, dn, t, what, relerr(got, gold))
                 else:
-                    # floors: the bf16 STATE carries 1 ulp (7.8e-3) of quantisation; P ~ q^2 and h ~ P see 2 ulp,
-                    # L ~ max (P g)^2 sees 4 ulp
-                    floor = 4e-2 if what.startswith("L") else 2e-2
+                    # relative to the reference-bf16's own error on the same inputs, plus a floor for the steps where that
+                    # error is still ~0 (first steps: Q = I exactly): 1 bf16 ulp (7.8e-3), 2 for L ~ max (P g)^2.  Observed on
+                    # MI355X (profiles/r01_l_parity_report.md): e_hip within 0.7 .. 1.1 x e_ref for P, L and h.
+                    floor = 2 * 7.8125e-3 if what.startswith("L") else 7.8125e-3
                     e_hip, e_ref = relerr(got, truth), relerr(gold, truth)
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
@@ -212,6 +213,83 @@ def test_kwns4_step_vs_golden(name):
                 else:
                     e_hip, e_ref = relerr(got_P, truth_P), relerr(gold_P, truth_P)
                     assert e_hip <= 1.5 * e_ref + 1e-2, (name, t, i, j, "P", e_hip, e_ref)
+
+
+@pytest.mark.parametrize("name", golden_names("kronwhiten_"))
+def test_kronwhiten_step_vs_golden(name):
+    """psgd_torch_amd.KronWhiten.step(closure) against fixtures captured from psgd.KronWhiten.step (psgd.py:589-654) with the
+    reference's recorded draws replayed: on-the-fly initial scale (:599-602), momentum on / off, whitening the gradient or the
+    momentum, update first / last, gated updates, per-tensor clipping (:642-651), dQ = Q0.5EQ1.5 and QUAD4P.  fp32."""
+    amd = _amd()
+    from test_oracle_golden import kronwhiten_kw_from_golden
+    z = load(name)
+    kw = kronwhiten_kw_from_golden(z)
+    p4 = kw.get("dQ") == "QUAD4P"
+    n, Tn = int(z["nparams"]), int(z["T"])
+    params = [torch.nn.Parameter(T(z[f"p{i}_init"], torch.float32).to(DEV)) for i in range(n)]
+    shapes = [tuple(p.squeeze().shape) for p in params]
+    kinds = [orc.kron_factor_kinds(s, kw.get("preconditioner_max_size", float("inf")), kw.get("preconditioner_max_skew", 1.0))
+             for s in shapes]
+    opt = amd.KronWhiten(params, **kw)
+    for t in range(Tn):
+        nd, k = int(z[f"t{t}_ndraws"]), 1
+        gates = iter([float(z[f"t{t}_draw0"])])
+        opt._uniform = lambda: next(gates)
+        per = []
+        if nd > 1:
+            for kd, shp in zip(kinds, shapes):
+                d = {"g": z[f"t{t}_draw{k}"].reshape(shp), "spd": {}, "skh": {}}; k += 1
+                for i, kind in enumerate(kd):
+                    if kind == "dense":
+                        d["spd"][i] = z[f"t{t}_draw{k}"]; k += 1
+                        if not p4:
+                            d["skh"][i] = z[f"t{t}_draw{k}"]; k += 1
+                d["u"] = float(z[f"t{t}_draw{k}"]); k += 1
+                per.append(d)
+            assert k == nd
+
+        def replay(idx, per=per):
+            g = [torch.from_numpy(per[i]["g"]).to(DEV) for i in idx]
+            spd = {(kk, j): torch.from_numpy(x).to(DEV) for kk, i in enumerate(idx) for j, x in per[i]["spd"].items()}
+            skh = {(kk, j): torch.from_numpy(x).to(DEV) for kk, i in enumerate(idx) for j, x in per[i]["skh"].items()}
+            return dict(noise=(g, spd, skh), balance_mask=[per[i]["u"] < 0.01 for i in idx])
+        opt._replay = replay
+        cs = [T(z[f"t{t}_g{i}"], torch.float32).to(DEV) for i in range(n)]
+        opt.step(lambda: sum((p * c).sum() for p, c in zip(params, cs)))
+        for i in range(n):
+            assert relerr(params[i].data, z[f"t{t}_p{i}"]) <= 2e-6 * (t + 1), (name, t, i, "p", relerr(params[i].data, z[f"t{t}_p{i}"]))
+            if f"t{t}_m{i}" in z.files:
+                eng, kk = opt._engines[0][0], opt._engines[0][1].index(i)
+                assert relerr(eng.ema[kk].reshape(-1), z[f"t{t}_m{i}"].reshape(-1)) <= 1e-6, (name, t, i, "m")
+            Q, Ls = opt._QLs[i]
+            for j in range(len(Q)):
+                gold_Q = torch.from_numpy(z[f"t{t}_p{i}_Q{j}"])
+                if p4:        # the factor IS P (symmetric): no gauge freedom, compare it directly
+                    assert relerr(Q[j], gold_Q) <= 3e-5 * (t + 1), (name, t, i, j, "P", relerr(Q[j], gold_Q))
+                else:
+                    assert relerr(P_of([Q[j]])[0], P_of([gold_Q])[0]) <= 3e-5 * (t + 1), (name, t, i, j, "P")
+                assert relerr(Ls[j], z[f"t{t}_p{i}_L{j}"]) <= 3e-5 * (t + 1), (name, t, i, j, "L")
+
+
+def test_kronwhiten_buckets_mixed_dtypes():
+    """Parameters of different dtypes go to separate engines (each tensor's factors live in its own dtype, psgd.py:558,602)
+    instead of being read with the first tensor's element type."""
+    amd = _amd()
+    g = torch.Generator().manual_seed(0)
+    params = [torch.nn.Parameter((0.3 * torch.randn(24, 16, generator=g)).to(DEV)),
+              torch.nn.Parameter((0.3 * torch.randn(16, generator=g)).to(DEV).to(torch.bfloat16)),
+              torch.nn.Parameter((0.3 * torch.randn(12, 12, generator=g)).to(DEV))]
+    tgt = [torch.randn(p.shape, generator=g).to(DEV).to(p.dtype) for p in params]
+    opt = amd.KronWhiten(params, preconditioner_init_scale=1.0, lr_params=0.05, lr_preconditioner=0.3, momentum=0.9, whiten_grad=False)
+
+    def closure():
+        return sum(((p.float() - c.float()) ** 2).sum() for p, c in zip(params, tgt))
+    l0 = float(closure())
+    for _ in range(30):
+        opt.step(closure)
+    assert len(opt._engines) == 2 and sorted(i for _, idx in opt._engines for i in idx) == [0, 1, 2]
+    assert opt._QLs[1][0][0].dtype == torch.bfloat16 and opt._QLs[0][0][0].dtype == torch.float32
+    assert float(closure()) < 0.5 * l0 and all(bool(torch.isfinite(p).all()) for p in params)
 
 
 @pytest.mark.parametrize("shape,max_skew", [((96, 64), 1.0), ((64, 64), 1.0), ((200,), 1.0), ((48, 80), 0.0),

@@ -24,6 +24,13 @@ def _engine(n_factors, width, dt):
     eng = amd.KronEngine([(4 * width, width)] * n_factors, DEV, precond_dtype=dt, use_momentum=False, init_scale=1.0)
     g = torch.Generator().manual_seed(1)
     grads = [(0.3 * torch.randn(4 * width, width, generator=g)).to(dt).to(DEV) for _ in range(n_factors)]
+    # Q = I gives an exactly symmetric Q' and hence R = Q'^T - Q' = 0: start from a visibly non-symmetric Q so that the skh chain
+    # (A = R) iterates on real data as well
+    for t in range(n_factors):
+        q = eng.Q[t][1]
+        assert q.dim() == 2
+        q.add_((0.05 * torch.randn(width, width, generator=g)).to(dt).to(DEV))
+    eng.state_changed()
     eng.accumulate(grads, keep_grad=True)
     eng.update_precond(L.SRC_GRAD, 0.5, 0.9, 1e-9, seed=3, offset=0, balance_mask=[False] * n_factors)   # fills term1, R, row stats
     torch.cuda.synchronize()
@@ -73,7 +80,7 @@ def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
             worst_v = torch.maximum(worst_v, dv)
             worst_s = torch.maximum(worst_s, ds)
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(v_ref.float()).all()) and float(v_ref.float().abs().max()) > 0
+    assert bool(torch.isfinite(v_ref.float()).all()) and float(v_ref.float().abs().max()) > 0      # (chain 1: A = R)
     assert float(worst_s) <= 1e-5, float(worst_s)
     assert float(worst_v) <= 4 * ulp, (float(worst_v), ulp)
     assert eng.info()["nlb_fallbacks"] == 0 and eng.info()["nlb_coop"] == 1

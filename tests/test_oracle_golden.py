@@ -262,3 +262,65 @@ def test_lrawhiten_step(name):
             assert relerr(params[i], z[f"t{t}_p{i}"]) <= 1e-6
         for k, nm in enumerate(("U", "V", "d")):
             assert relerr(opt.UVd[k], z[f"t{t}_{nm}"]) <= 2e-5
+
+
+def kronwhiten_kw_from_golden(z):
+    kw = {}
+    for k in z.files:
+        if not k.startswith("kw_"):
+            continue
+        nm, v = k[3:], z[k]
+        if nm == "dQ":
+            kw[nm] = str(v)
+        elif nm == "grad_clip_max_amps":
+            kw[nm] = tuple(float(x) for x in v)
+        elif v.dtype == np.bool_:
+            kw[nm] = bool(v)
+        else:
+            kw[nm] = None if np.isnan(float(v)) else float(v)
+    return kw
+
+
+class KronWhitenReplay(DrawReplay):
+    """The recorded draw stream of one KronWhiten.step (psgd.py:589-654): the gate, then per updated tensor randn_like(G),
+    per dense factor the spd draw (+ the skh draw for Q0.5EQ1.5; QUAD4P has no Procrustes step), the balancing rand([])."""
+
+    def __init__(self, z, t, p4):
+        super().__init__(z, t)
+        self.p4 = p4
+
+    def noise_for(self, G, kinds):
+        g_noise = T(self._next("randn"), G.dtype).reshape(G.shape)
+        spd, skh = [], []
+        for kind in kinds:
+            if kind == "dense":
+                spd.append(T(self._next("randn"), G.dtype))
+                skh.append(None if self.p4 else T(self._next("randn"), G.dtype))
+            else:
+                spd.append(None)
+                skh.append(None)
+        return orc.KronNoise(g_noise, spd, skh, float(self._next("rand")))
+
+
+@pytest.mark.parametrize("name", golden_names("kronwhiten_"))
+def test_kronwhiten_step(name):
+    """KronWhitenOracle (psgd.py:589-654 restated) against fixtures captured from psgd.KronWhiten.step itself: on-the-fly
+    initial scale, all-updates-then-all-applies draw order, per-tensor clipping, momentum on/off, gated updates, QUAD4P."""
+    z = load(name)
+    kw = kronwhiten_kw_from_golden(z)
+    n, Tn = int(z["nparams"]), int(z["T"])
+    params = [T(z[f"p{i}_init"], torch.float32).clone() for i in range(n)]
+    replay = {"cur": None}
+    opt = orc.KronWhitenOracle(params, uniform=lambda: replay["cur"].uniform(),
+                               noise_for=lambda G, kinds: replay["cur"].noise_for(G, kinds), **kw)
+    for t in range(Tn):
+        replay["cur"] = KronWhitenReplay(z, t, kw.get("dQ") == "QUAD4P")
+        opt.step([T(z[f"t{t}_g{i}"], torch.float32) for i in range(n)])
+        assert replay["cur"].k == replay["cur"].n, "draw count differs from the reference"
+        for i in range(n):
+            assert relerr(params[i], z[f"t{t}_p{i}"]) <= 1e-6, (name, t, i, "p")
+            if opt.ms is not None:
+                assert relerr(opt.ms[i], z[f"t{t}_m{i}"]) <= TOL["fp32"]
+            for j, (q, ell) in enumerate(zip(*opt.QLs[i])):
+                assert relerr(q, z[f"t{t}_p{i}_Q{j}"]) <= TOL["fp32"], (name, t, i, j, "Q")
+                assert relerr(ell, z[f"t{t}_p{i}_L{j}"]) <= TOL["fp32"], (name, t, i, j, "L")
