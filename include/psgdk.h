@@ -250,7 +250,7 @@ int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches
 /* test hook: ONE norm lower bound (psgd.py:46-93; chain 0 = spd on term1, 1 = skh on R) of every dense factor on the plan's
  * CURRENT work arena (i.e. after a psgdk_update_precond_q0p5eq1p5 call), by the cooperative launch (route 1) or the multi-launch
  * route (route 0), Philox noise (seed, offset).  Copies the four products' row sums of squares ([F][4][32] fp32) to out_vsq and
- * the last subspace block ([F][32][max_dense_dim] of the preconditioner dtype, rows padded with zeros) to out_v (device
+ * the last two subspace blocks ([F][2][32][max_dense_dim] of the preconditioner dtype: products 4 and 3; rows padded with zeros) to out_v (device
  * pointers, either may be NULL).  inject_fault != 0 makes member 1 of every multi-member factor skip its arrivals, to exercise
  * the timeout path (route 1 only). */
 int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
@@ -258,6 +258,8 @@ int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64
 int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,
                        int ldb, int ldc, int ldct, int symmetric, void* stream);
 /* times `iters` launches of a batch of identical dense problems (contiguous operands) with hipEvents: avg ms/launch */
+int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, float* avg_ms, void* stream);
+int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int flags, void* stream);
 int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
                           int symmetric, int iters, float* avg_ms, void* stream);
 

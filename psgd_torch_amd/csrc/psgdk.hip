@@ -22,7 +22,9 @@ struct Stage {                       // one grouped GEMM launch
     GemmProblem* d_probs = nullptr;
     GemmTile* d_tiles = nullptr;
     unsigned n_tiles = 0;
-    bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_big_kernel)
+    bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_pipe_kernel; gemm_nt_big_kernel with `lock`)
+    bool lock = false;               // tests / experiments: the lock-step main loop of the 256x256 tiling
+    bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
 };
 
@@ -132,10 +134,36 @@ int finish_stage(Stage& s) {
     return upload(&s.d_tiles, tiles);
 }
 
+// experiment switches (read once): PSGDK_GEMM_BIG=lock selects the lock-step main loop of the 256 x 256 tiling instead of the
+// staggered-phase one; PSGDK_BIG_MIN_TILES moves the number of 256 x 256 tiles from which a stage uses that tiling
+static bool big_lockstep() {
+    static const int v = [] { const char* e = getenv("PSGDK_GEMM_BIG"); return (e && e[0] == 'l') ? 1 : 0; }();
+    return v != 0;
+}
+static int64_t big_min_tiles() {      // (read at every bind: the tests force the big tiling onto small plans with it)
+    const char* e = getenv("PSGDK_BIG_MIN_TILES");
+    return e ? (int64_t)atoll(e) : (int64_t)768;
+}
+
+// the staggered-phase kernel runs persistently (one workgroup per CU walks the tile table) unless PSGDK_GEMM_PERSIST=0 or the
+// stage asks for one workgroup per tile (experiments)
+static unsigned persistent_grid(unsigned n_tiles) {
+    static const int cus = [] {
+        const char* e = getenv("PSGDK_GEMM_PERSIST");
+        if (e && e[0] == '0') return 0;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n - n % 8;          // a multiple of 8: a workgroup's stride keeps it on one XCD's queue of the interleaved table
+    }();
+    return (cus > 0 && n_tiles > (unsigned)cus) ? (unsigned)cus : n_tiles;
+}
+
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
-    if (s.big) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
+    if (s.big && (s.lock || big_lockstep())) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
+    else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
+                                       s.d_probs, s.d_tiles, (int)s.n_tiles);
     else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
 }
@@ -752,7 +780,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
             nb += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
         }
-        s->big = nb >= 768;
+        s->big = nb >= big_min_tiles();
     }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
@@ -1420,7 +1448,8 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
-    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling
+    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop
+    s.lock = (symmetric & 2048) != 0;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -1433,6 +1462,71 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     if (s.d_probs) (void)hipFree(s.d_probs);
     if (s.d_tiles) (void)hipFree(s.d_tiles);
     return rc;
+}
+
+// experiments: a stage of a bound plan launched `iters` times back to back (hipEvent-timed), as the step launches it or with another
+// main loop / launch shape: variant 0 = as bound, 1 = lock-step 256x256, 2 = staggered with one workgroup per tile, 3 = 128x128 tiling
+int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, float* avg_ms, void* stream) {
+    if (!plan || !plan->state || iters <= 0 || !avg_ms) return PSGDK_ERR_INVALID;
+    Stage* list[] = {&plan->g_upd_a, &plan->g_app_a[0], &plan->g_gram, &plan->g_qupd, &plan->g_rq, &plan->g_rrq, &plan->g_P, &plan->g_upd_b, &plan->g_app_b};
+    if (which < 0 || which >= (int)(sizeof(list) / sizeof(list[0]))) return PSGDK_ERR_INVALID;
+    Stage s = *list[which];              // shallow copy: shares the device tables unless the tiling changes
+    Stage alt;
+    if (variant == 1) s.lock = true;
+    if (variant == 2) s.one_per_tile = true;
+    if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
+    if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
+    if (variant >= 5 && variant <= 8) {      // same tiling, parts of the epilogue's work stripped / the output discarded
+        alt.probs = s.probs; alt.big = s.big;
+        for (auto& q : alt.probs) {
+            if (variant == 5 || variant == 6) { q.row_sumsq = nullptr; q.sumsq = nullptr; }
+            if (variant == 6) { q.row_scale = nullptr; q.flags &= ~(GF_SQ_ROWSCALE | GF_RSQRT_ROWSCALE); }
+            if (variant == 7) q.flags |= GF_DBG_NOSTORE;
+            if (variant == 8) q.flags |= GF_DBG_NOEPI;
+        }
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) { if (plan->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st); }
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < iters; ++i) { if (plan->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st); }
+    (void)hipEventRecord(e1, st);
+    int rc = PSGDK_OK;
+    if (hipEventSynchronize(e1) != hipSuccess) rc = PSGDK_ERR_HIP;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (alt.d_probs) (void)hipFree(alt.d_probs);
+    if (alt.d_tiles) (void)hipFree(alt.d_tiles);
+    return rc;
+}
+
+// experiments: ONE asynchronous launch of a one-problem stage (tables cached per argument set, never freed: tools only)
+int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int flags, void* stream) {
+    struct Key { const void* a; const void* b; void* c; void* ct; int dtype, M, N, K, flags; };
+    static std::vector<std::pair<Key, Stage*>> cache;
+    Stage* s = nullptr;
+    for (auto& e : cache)
+        if (e.first.a == A && e.first.b == B && e.first.c == C && e.first.ct == Ct && e.first.dtype == dtype && e.first.M == M &&
+            e.first.N == N && e.first.K == K && e.first.flags == flags) s = e.second;
+    if (!s) {
+        s = new Stage();
+        GemmProblem P{};
+        P.A = A; P.B = B; P.C = C; P.Ct = Ct; P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = K; P.ldc = N; P.ldct = M; P.alpha = 1.f;
+        P.flags = flags & ~(1024 | 2048 | 16384);
+        if (!C && Ct) P.flags |= GF_TMAJOR;
+        s->probs.push_back(P);
+        s->big = (flags & 1024) != 0; s->lock = (flags & 2048) != 0; s->one_per_tile = (flags & 16384) != 0;
+        int rc = finish_stage(*s);
+        if (rc) return rc;
+        cache.push_back({Key{A, B, C, Ct, dtype, M, N, K, flags}, s});
+    }
+    if (dtype == PSGDK_BF16) launch_stage_t<bf16_t>(*s, (hipStream_t)stream); else launch_stage_t<float>(*s, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
 }
 
 int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
@@ -1454,7 +1548,9 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
         s.probs.push_back(P);
     }
     s.big = (symmetric & 1024) != 0;
-    for (auto& q : s.probs) q.flags &= ~1024;
+    s.lock = (symmetric & 2048) != 0;
+    s.one_per_tile = (symmetric & 16384) != 0;
+    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;

@@ -90,9 +90,14 @@ def _noise_to_dev(noise, dt):
 KRON_2D = golden_names("kron_")       # <= 2-D tensors (grouped-GEMM path) and N-D tensors (mode-product path)
 
 
+@pytest.mark.parametrize("force_big", [0, 1])
 @pytest.mark.parametrize("name", KRON_2D)
-def test_functional_seam_vs_golden(name):
+def test_functional_seam_vs_golden(name, force_big, monkeypatch):
+    """force_big = 1: every grouped-GEMM stage of the plan on the 256x256 tiling (staggered-phase main loop, register-direct
+    epilogue for the one-output products) -- which plans otherwise use only from 768 tiles per launch, i.e. at bench size."""
     amd = _amd()
+    if force_big:
+        monkeypatch.setenv("PSGDK_BIG_MIN_TILES", "1")          # read when a plan is bound
     z = load(name)
     shape = tuple(int(s) for s in z["shape"])
     Tn = int(z["T"])

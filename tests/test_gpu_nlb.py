@@ -46,43 +46,51 @@ def _run_bound(eng, chain, route, seed, vsq, v, fault=0):
 @pytest.mark.parametrize("dt,width,n_factors,iters", [(torch.bfloat16, 768, 62, 1000), (torch.float32, 384, 40, 300),
                                                        (torch.bfloat16, 320, 24, 300)])
 def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
-    """GPT-2-small's plan (62 factors x 768, S = 3) and two other widths: 2 chains x iters bounds, a saturating side stream,
-    each launch compared with the multi-launch route on the same inputs and noise.  The two routes share MFMA, K order and
-    rounding points; they differ only through the order of the fp32 row-sum atomics, i.e. by ~1 ulp of fp32 in the row scales,
-    which can flip the rounding of an element of V: bounded by a few ulp of the element type on V, 1e-5 on the sums."""
+    """GPT-2-small's plan (62 factors x 768, S = 3) and two other widths: 2 chains x iters bounds with fresh noise each, a
+    saturating side stream (siblings start at different times), consumers L1-warm by construction (the two exchange buffers
+    are re-read every second product of a launch), each launch compared ELEMENT BY ELEMENT with the multi-launch route on the
+    same inputs -- the last two blocks of the iteration, all four products' row sums.
+    What a correct exchange may differ by: the routes share MFMA, K order and rounding points, but accumulate the fp32 row sums
+    with atomics, whose order is free -- in BOTH routes: two runs of the SAME route differ as much as the two routes do
+    (tools/nlb_diag.py: row sums 1e-4 in bf16 / 5e-7 in fp32, a few hundred elements of V by one ulp).  A 1-ulp-of-fp32 change of
+    a row scale flips the rounding of some elements of the next block by one ulp of the element type.
+    What a stale word would look like: two bf16 elements of a block replaced by the previous contents of that exchange buffer
+    (the block of two products earlier): an O(1) error on them, and ~ 1/sqrt(d) = 4 % of a typical element on 256 elements of
+    the next block.  Bound: no element off by more than 2 ulp of its row's largest element."""
     eng, _ = _engine(n_factors, width, dt)
     info = eng.info()
     assert info["nlb_coop"] == 1, info
     F, dp = info["dense_factors"], info["max_dense_dim"]
     vsq_ref = torch.zeros(F, 4, 32, device=DEV)
-    v_ref = torch.zeros(F, 32, dp, device=DEV, dtype=dt)
+    v_ref = torch.zeros(F, 2, 32, dp, device=DEV, dtype=dt)
     vsq = torch.zeros_like(vsq_ref)
     v = torch.zeros_like(v_ref)
     # unrelated work on a second stream: large matmuls that keep all CUs occupied and make the siblings' start times uneven
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
-    stop = {"n": 0}
     worst_v = torch.zeros((), device=DEV)
     worst_s = torch.zeros((), device=DEV)
-    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -22
+    nonzero = torch.zeros((), device=DEV)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -22          # of the row's largest element (its binade's upper end)
     for chain in (0, 1):
         for it in range(iters):
             if it % 4 == 0:
                 with torch.cuda.stream(side):
                     for _ in range(3):
                         a = (a @ a).clamp_(-1, 1)
-                    stop["n"] += 1
-            seed = 1000 * chain + it // 2          # every noise draw is used twice: the second launch re-reads warm lines
+            seed = 100000 * chain + it
             _run_bound(eng, chain, 0, seed, vsq_ref, v_ref)
             _run_bound(eng, chain, 1, seed, vsq, v)
-            dv = (v.float() - v_ref.float()).abs().amax() / v_ref.float().abs().amax().clamp_min(1e-30)
+            rowmax = v_ref.float().abs().amax(dim=-1, keepdim=True)
+            dv = ((v.float() - v_ref.float()).abs() / rowmax.clamp_min(1e-30)).amax()
             ds = ((vsq - vsq_ref).abs() / vsq_ref.abs().clamp_min(1e-30)).amax()
             worst_v = torch.maximum(worst_v, dv)
             worst_s = torch.maximum(worst_s, ds)
+            nonzero = torch.maximum(nonzero, rowmax.amin())
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(v_ref.float()).all()) and float(v_ref.float().abs().max()) > 0      # (chain 1: A = R)
-    assert float(worst_s) <= 1e-5, float(worst_s)
-    assert float(worst_v) <= 4 * ulp, (float(worst_v), ulp)
+    assert bool(torch.isfinite(v_ref.float()).all()) and float(nonzero) > 0      # (every row of every block carried data)
+    assert float(worst_v) <= 2 * ulp, (float(worst_v), ulp)
+    assert float(worst_s) <= (1e-2 if dt == torch.bfloat16 else 2e-5), float(worst_s)
     assert eng.info()["nlb_fallbacks"] == 0 and eng.info()["nlb_coop"] == 1
 
 
@@ -95,7 +103,7 @@ def test_cooperative_bound_timeout_is_reported_and_falls_back():
     assert eng.info()["nlb_coop"] == 1
     F, dp = eng.info()["dense_factors"], eng.info()["max_dense_dim"]
     vsq = torch.zeros(F, 4, 32, device=DEV)
-    v = torch.zeros(F, 32, dp, device=DEV, dtype=torch.bfloat16)
+    v = torch.zeros(F, 2, 32, dp, device=DEV, dtype=torch.bfloat16)
     _run_bound(eng, 0, 1, 5, vsq, v, fault=1)
     torch.cuda.synchronize()          # (the word is written by the kernel; the library itself never synchronises for it)
     q_before = [q.clone() for q in eng.Q[0]]
