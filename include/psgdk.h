@@ -191,6 +191,11 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream);
 int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, float lr, float decoupled_wd,
                        float max_avg_amp, float max_elem_amp, void* stream);
 
+/* Sharded path (build-side design): the clipped preconditioned gradients (wrapped_as_torch_optimizer_for_ddp.py:153-156)
+ * of ALL tensors of the plan, exported in one launch to caller buffers outs[t] (logical contiguous order, element type
+ * out_dtype) -- normally this rank's slices of the flat all-gather buffer. */
+int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype, int clip, float max_avg_amp, float max_elem_amp,
+                              void* stream);
 /* copy h of tensor t to `out` (logical layout, contiguous, out_dtype) -- the return value of precond_grad_kron.
  * clip != 0 applies the ..._ddp.py:153-156 clipping first (used by the sharded path to ship clipped h). */
 int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "psgdk_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_apply_update": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_void_p]),
+    "psgdk_export_precond_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "psgdk_read_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_void_p]),
     "psgdk_lra_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_int]),

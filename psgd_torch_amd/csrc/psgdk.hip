@@ -1351,8 +1351,7 @@ int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, con
                      float decoupled_wd, void* stream) {
     if (!flat || !params || !h_flat || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32) ||
         (h_dtype != PSGDK_BF16 && h_dtype != PSGDK_F32) || !(lr > 0.f) || !(decoupled_wd >= 0.f)) return PSGDK_ERR_INVALID;
-    for (int t = 0; t < flat->n; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream;      // (params[t] == NULL: tensor t is skipped this step)
     int rc;
     if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, (const void* const*)params, flat->n, st))) return rc;
     if (flat->n_chunks)
@@ -1371,6 +1370,21 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(e - b), dim3(256), 0, st, plan->d_td, plan->d_tiles_all + b,
                                         (void* const*)plan->d_ptr_a, out_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, out));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype, int clip, float max_avg_amp, float max_elem_amp,
+                              void* stream) {
+    if (!plan || !outs || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    for (int t = 0; t < plan->n_tensors; ++t) if (!outs[t]) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rcp;
+    if ((rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)outs, plan->n_tensors, st))) return rcp;
+    DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td, plan->d_tiles_all,
+                                        (void* const*)plan->d_ptr_b, out_dtype, plan->work,
+                                        (const float*)(plan->work + plan->hsumsq_off), 2, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, (void*)nullptr));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }

@@ -89,14 +89,19 @@ class FlatApply:
             pass
 
     def apply(self, params: Sequence[torch.Tensor], flat: torch.Tensor, lr: float, decoupled_wd: float):
-        _check_tensors("params", params, self.numels, self.device)
+        live = [(p, n) for p, n in zip(params, self.numels) if p is not None]      # None: skipped this step
+        _check_tensors("params", [p for p, _ in live], [n for _, n in live], self.device)
+        if len(params) != self.n:
+            raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"params: expected {self.n} entries, got {len(params)}")
         if not flat.is_contiguous() or flat.device != self.device:
             raise L.PsgdkError(L.PSGDK_ERR_INVALID, "the gathered buffer must be a contiguous tensor on the engine's device")
         pa = L.ptr_array(params)
         self._keep = (pa, list(params), flat)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        L.check(self.lib.psgdk_flat_apply(self._h, pa, L.dtype_code(params[0].dtype), flat.data_ptr(), L.dtype_code(flat.dtype),
+        if not live:
+            return
+        L.check(self.lib.psgdk_flat_apply(self._h, pa, L.dtype_code(live[0][0].dtype), flat.data_ptr(), L.dtype_code(flat.dtype),
                                           float(lr), float(decoupled_wd), st), "flat_apply")
 
 
@@ -316,6 +321,16 @@ class KronEngine:
         L.check(self.lib.psgdk_read_precond_grad(self._plan, t, out.data_ptr(), L.dtype_code(out.dtype), int(clip),
                                                  float(max_avg_amp), float(max_elem_amp), self._stream()), "read_h")
         return out
+
+    @_on_device
+    def export_precond_grad(self, outs: Sequence[torch.Tensor], clip: bool = True, max_avg_amp: float = 2.0, max_elem_amp: float = 10.0):
+        """All tensors' (clipped) preconditioned gradients into caller buffers, ONE launch (the sharded path's export into the
+        rank's segment of the all-gather buffer)."""
+        dt = _check_tensors("outs", outs, self.numels, self.device)
+        oa = L.ptr_array(outs)
+        self._keep_o = [oa, list(outs)]
+        L.check(self.lib.psgdk_export_precond_grad(self._plan, oa, L.dtype_code(dt), int(clip), float(max_avg_amp), float(max_elem_amp),
+                                                   self._stream()), "export_precond_grad")
 
     def info(self):
         """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / how often a timeout switched it off."""

@@ -115,6 +115,7 @@ class KWNS4(torch.optim.Optimizer):
         self._replay = None
         self._split = set()          # bucket keys that fell back to one engine per parameter
         self._split_pd = {}
+        self._split_owner = {}       # sharded mode: owner rank of every split-off parameter (kept from the batched bucket)
 
     # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
     # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
@@ -154,14 +155,11 @@ class KWNS4(torch.optim.Optimizer):
             for p in plist:
                 sk = key + ("p", pos[id(p)])
                 if sk not in self._buckets:
-                    self._bucket_for(gi, group, [p], key=sk, pd=self._split_pd.get(key))
+                    self._bucket_for(gi, group, [p], key=sk, pd=self._split_pd.get(key), owner=self._split_owner.get(sk))
                 out.append((self._buckets[sk], [p]))
             return out
         b = self._buckets.get(key)
         if b is not None and [id(p) for p in b.params] != [id(p) for p in plist]:
-            if self.shard_state:
-                raise RuntimeError("KWNS4 (HIP engine, shard_state=True): the set of parameters with gradients changed "
-                                   "between steps; per-step parameter skipping is only built for the replicated mode")
             self._split_bucket(gi, group, key, b, pos)
             return self._buckets_for(gi, group, plist)
         return [(self._bucket_for(gi, group, plist), plist)]
@@ -170,23 +168,28 @@ class KWNS4(torch.optim.Optimizer):
         self._split.add(key)
         self._split_pd[key] = b.pd
         del self._buckets[key]
+        # (sharded mode: every parameter keeps its owner; the state lives -- and is carried over -- on that rank only)
+        local = {i: k for k, i in enumerate(b.owned)}
         for k, p in enumerate(b.params):
             sk = key + ("p", pos[id(p)])
-            nb = self._bucket_for(gi, group, [p], key=sk, shapes=[b.shapes[k]], pd=b.pd)
+            self._split_owner[sk] = [b.owner[k]]
+            nb = self._bucket_for(gi, group, [p], key=sk, shapes=[b.shapes[k]], pd=b.pd, owner=[b.owner[k]])
             nb.step = b.step
             self.state[p]["step"] = b.step
-            oldQ, oldL = b.engine.QL(k)
+            if nb.engine is None:
+                continue
+            oldQ, oldL = b.engine.QL(local[k])
             newQ, newL = nb.engine.QL(0)
             for src, dst in zip(oldQ, newQ):
                 dst.copy_(src)
             for src, dst in zip(oldL, newL):
                 dst.copy_(src)
             if group["momentum"] > 0.0:
-                nb.engine.ema[0].copy_(b.engine.ema[k])
+                nb.engine.ema[0].copy_(b.engine.ema[local[k]])
             nb.engine.state_changed()
         b.engine = None
 
-    def _bucket_for(self, gi: int, group, plist: List[torch.Tensor], key=None, shapes=None, pd=None) -> _Bucket:
+    def _bucket_for(self, gi: int, group, plist: List[torch.Tensor], key=None, shapes=None, pd=None, owner=None) -> _Bucket:
         p0 = self._data_of(plist[0])
         if key is None:
             key = (gi, p0.dtype, self._grad_of(plist[0]).dtype, p0.device)
@@ -204,8 +207,9 @@ class KWNS4(torch.optim.Optimizer):
             shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]        # ..._ddp.py:124
         b.pd = pd
         if self.shard_state:
-            costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
-            owner = lpt_partition(costs, self.world)
+            if owner is None:
+                costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
+                owner = lpt_partition(costs, self.world)
             b.owner = owner
             b.owned = [i for i, o in enumerate(owner) if o == self.rank]
         else:
@@ -297,19 +301,25 @@ class KWNS4(torch.optim.Optimizer):
             if not self.shard_state:
                 eng.apply_update(own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
             else:
-                for k, i in enumerate(b.owned):
-                    eng.read_precond_grad(k, out=b.h_views[i], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
-            if updateP_last:
-                eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
-                                   offset=2 * t + 1, **self._update_draws(b, plist))
-        else:
-            if updateP_first or updateP_last:
-                [self._uniform() for _ in plist]          # keep the gate stream in lock-step with the owning ranks
+                # all owned tensors' clipped h straight into this rank's segment of the exchange buffer: one launch
+                eng.export_precond_grad([b.h_views[i] for i in b.owned], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
+        elif updateP_first or updateP_last:
+            [self._uniform() for _ in plist]              # keep the gate stream in lock-step with the owning ranks
+        work = None
         if self.shard_state:
-            # ONE exchange step: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner is)
+            # ONE exchange step: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner is), in place
+            # (RCCL's in-place form: the send buffer IS this rank's segment of the receive buffer) and asynchronous, so that
+            # an update_preconditioner_first=False update below runs while the fabric works
             mine = b.flat[self.rank * b.seg:(self.rank + 1) * b.seg]
-            torch.distributed.all_gather_into_tensor(b.flat, mine.clone())
-            lps = [self._data_of(p) for p in plist]
+            in_place = torch.distributed.get_backend() == "nccl"
+            work = torch.distributed.all_gather_into_tensor(b.flat, mine if in_place else mine.clone(), async_op=True)
+        if eng is not None and updateP_last:
+            eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
+                               offset=2 * t + 1, **self._update_draws(b, plist))
+        if self.shard_state:
+            work.wait()
+            present = {id(p) for p in plist}
+            lps = [self._data_of(p) if id(p) in present else None for p in b.params]
             b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
         b.step += 1
         for p in plist:

@@ -21,6 +21,8 @@ class _TorchFlatApply:
 
     def apply(self, params, flat, lr, decoupled_wd):
         for p, n, o in zip(params, self.numels, self.offsets):
+            if p is None:
+                continue
             if decoupled_wd:
                 p.mul_(1.0 - decoupled_wd * lr)
             p.subtract_(flat[o:o + n].view_as(p).to(p.dtype), alpha=lr)
@@ -114,6 +116,10 @@ class OracleEngine:
             return h.clone()
         out.copy_(h.reshape(out.shape))
         return out
+
+    def export_precond_grad(self, outs, clip=True, max_avg_amp=2.0, max_elem_amp=10.0):
+        for k, out in enumerate(outs):
+            self.read_precond_grad(k, out=out, clip=clip, max_avg_amp=max_avg_amp, max_elem_amp=max_elem_amp)
 
     def state_changed(self):
         pass

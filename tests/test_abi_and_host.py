@@ -196,7 +196,7 @@ def test_lpt_partition_properties():
     owner = lpt_partition(costs, 8)
     assert len(owner) == len(shapes) and set(owner) == set(range(8))
     loads = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(8)]
-    assert max(loads) / (sum(loads) / 8) < 1.15, "LPT must balance GPT-2-medium within 15% (SURVEY 8e)"
+    assert max(loads) / (sum(loads) / 8) <= 1.05, "LPT must balance GPT-2-medium within 5 % at world 8 (SURVEY 8e)"
     assert lpt_partition(costs, 8) == owner                      # deterministic on every rank
     # dense/diag rule agrees with the oracle's
     from psgd_torch_amd.sharding import kron_factor_kinds

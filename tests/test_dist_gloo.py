@@ -20,15 +20,19 @@ def _make(seed):
     return [torch.nn.Parameter(0.5 * torch.randn(s, generator=g)) for s in SHAPES]
 
 
-def _run(params, steps, shard, **kw):
+MISSING = [set(), {2}, set(), {0, 4}, {0, 4, 7}, set()]      # parameters WITHOUT a gradient, per step (the `missing` cases)
+
+
+def _run(params, steps, shard, missing=False, **kw):
     import psgd_torch_amd
     from oracle_engine import OracleEngine
     opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=shard,
                                lr_params=1e-2, **kw)
     g = torch.Generator().manual_seed(99)
-    for _ in range(steps):
-        for p in params:
-            p.grad = 0.3 * torch.randn(p.shape, generator=g)
+    for t in range(steps):
+        for i, p in enumerate(params):
+            gr = 0.3 * torch.randn(p.shape, generator=g)
+            p.grad = None if (missing and i in MISSING[t % len(MISSING)]) else gr
         opt.step()
     return opt
 
@@ -40,7 +44,7 @@ def _worker(rank, world, port, outdir, kw):
     try:
         torch.set_num_threads(1)
         params = _make(7)
-        opt = _run(params, 4, True, **kw)
+        opt = _run(params, 6 if kw.get("missing") else 4, True, **kw)
         owned = [len(b.owned) for b in opt._buckets.values()]
         torch.save({"params": [p.data.clone() for p in params], "owned": owned}, os.path.join(outdir, f"r{rank}.pt"))
     finally:
@@ -56,19 +60,23 @@ def _free_port():
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(whiten_grad=True, update_preconditioner_first=False, weight_decay=0.0),
-                                dict(preconditioner_update_probability=0.5, momentum=0.5)])
+                                dict(preconditioner_update_probability=0.5, momentum=0.5),
+                                dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02)])
 def test_sharded_equals_replicated(kw):
+    """(missing=True: some parameters have no gradient on some steps -- the reference skips them, ..._ddp.py:113-115; the
+    sharded optimizer splits its bucket per parameter, every parameter keeping its owner, and skips their update and decay.)"""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
         sys.path.insert(0, here)
     ref_params = _make(7)
-    _run(ref_params, 4, False, **kw)
+    _run(ref_params, 6 if kw.get("missing") else 4, False, **kw)
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, _free_port(), d, kw), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "r0.pt"))
         r1 = torch.load(os.path.join(d, "r1.pt"))
-    assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
+    if not kw.get("missing"):
+        assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
     for a, b, c in zip(r0["params"], r1["params"], ref_params):
         assert torch.equal(a, b), "ranks diverged"
         assert torch.allclose(a, c.data, rtol=0, atol=0), "sharded result differs from the single-process result"

@@ -89,7 +89,9 @@ def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
             nonzero = torch.maximum(nonzero, rowmax.amin())
     torch.cuda.synchronize()
     assert bool(torch.isfinite(v_ref.float()).all()) and float(nonzero) > 0      # (every row of every block carried data)
-    assert float(worst_v) <= 2 * ulp, (float(worst_v), ulp)
+    # (fp32: a 1-ulp change of a row scale moves EVERY element of the next block by up to an ulp, and two products follow it:
+    #  a few ulp in total; still four orders of magnitude below what a stale word would do)
+    assert float(worst_v) <= (2 * ulp if dt == torch.bfloat16 else 8 * ulp), (float(worst_v), ulp)
     assert float(worst_s) <= (1e-2 if dt == torch.bfloat16 else 2e-5), float(worst_s)
     assert eng.info()["nlb_fallbacks"] == 0 and eng.info()["nlb_coop"] == 1
 
