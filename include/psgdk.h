@@ -210,6 +210,17 @@ int psgdk_flat_create(psgdk_flat** out, int n, const int64_t* numel, const int64
 int psgdk_flat_destroy(psgdk_flat* flat);
 int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
                      float decoupled_wd, void* stream);
+/* LRAWhiten.step's vector work around the preconditioner (psgd.py:1142-1155, 1179-1187), one launch each over ALL parameters of
+ * the flat layout (h_offset[t] = running sum of numel: the concatenation order of psgd.py:1142):
+ * psgdk_flat_gather: g_flat[off_t + i] = grads[t][i] (cast to flat_dtype); if m_flat: m <- beta m + (1 - beta) g in place
+ *   (psgd.py:1153); if sum_g4_dev: *sum_g4_dev = sum g^4 (the on-the-fly scale of d, psgd.py:1144-1145).
+ * psgdk_flat_apply_clipped: params[t] -= lr * clip(h)[off_t..]: h scaled by max_avg_amp / rms(h) when rms(h) = sqrt(*h_sumsq_dev /
+ *   h_numel) exceeds max_avg_amp, then clamped to +-max_elem_amp (psgd.py:1179-1187).  psgdk_lra_last_sumsq returns the device
+ *   word into which psgdk_lra_precond_grad accumulated the sum of squares of its last output. */
+int psgdk_flat_gather(psgdk_flat* flat, const void* const* grads, int grad_dtype, void* g_flat, int flat_dtype, void* m_flat, float beta,
+                      float* sum_g4_dev, void* stream);
+int psgdk_flat_apply_clipped(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                             const float* h_sumsq_dev, int64_t h_numel, float max_avg_amp, float max_elem_amp, void* stream);
 
 /* fill `out` with the engine's N(0,1) stream (same generator the fused kernels use), for statistical tests. */
 int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t offset, uint32_t stream_id,
@@ -232,6 +243,8 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
                             float lr, float betaL, float damping, void* stream);
 /* replaces psgd.precond_grad_lra (psgd.py:1055-1063): out = Q^T Q g. */
 int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream);
+/* device word holding the sum of squares of the last psgdk_lra_precond_grad output (see psgdk_flat_apply_clipped) */
+int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr);
 
 /* ---- introspection (bench.py / tests; no reference counterpart): how the plan runs.  NLB_COOP: the norm lower bounds
  * (psgd.py:46-93) run as one cooperative launch per bound instead of start block + 4 grouped-GEMM products + scalars (set at

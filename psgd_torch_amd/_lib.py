@@ -88,6 +88,11 @@ SIGNATURES = {
     "psgdk_flat_destroy": (C.c_int, [C.c_void_p]),
     "psgdk_flat_apply": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                    C.c_void_p]),
+    "psgdk_flat_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
+    "psgdk_flat_apply_clipped": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+                                           C.c_float, C.c_float, C.c_void_p]),
+    "psgdk_lra_last_sumsq": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "psgdk_fill_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "psgdk_test_nlb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

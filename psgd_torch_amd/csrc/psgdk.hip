@@ -1356,10 +1356,42 @@ int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, con
     if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, (const void* const*)params, flat->n, st))) return rc;
     if (flat->n_chunks)
         hipLaunchKernelGGL(flat_apply_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks, (void* const*)flat->d_ptrs,
-                           param_dtype, h_flat, h_dtype, lr, 1.0f - decoupled_wd * lr);
+                           param_dtype, h_flat, h_dtype, lr, 1.0f - decoupled_wd * lr, (const float*)nullptr, 1.f, 0.f, 0.f);
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }
+
+int psgdk_flat_apply_clipped(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                             const float* h_sumsq_dev, int64_t h_numel, float max_avg_amp, float max_elem_amp, void* stream) {
+    if (!flat || !params || !h_flat || !h_sumsq_dev || h_numel <= 0 || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32) ||
+        (h_dtype != PSGDK_BF16 && h_dtype != PSGDK_F32) || !(lr > 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f))
+        return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, (const void* const*)params, flat->n, st))) return rc;
+    if (flat->n_chunks)
+        hipLaunchKernelGGL(flat_apply_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks, (void* const*)flat->d_ptrs,
+                           param_dtype, h_flat, h_dtype, lr, 1.0f, h_sumsq_dev, (float)h_numel, max_avg_amp, max_elem_amp);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_flat_gather(psgdk_flat* flat, const void* const* grads, int grad_dtype, void* g_flat, int flat_dtype, void* m_flat, float beta,
+                      float* sum_g4_dev, void* stream) {
+    if (!flat || !grads || !g_flat || (grad_dtype != PSGDK_BF16 && grad_dtype != PSGDK_F32) ||
+        (flat_dtype != PSGDK_BF16 && flat_dtype != PSGDK_F32) || !(beta >= 0.f && beta < 1.f)) return PSGDK_ERR_INVALID;
+    for (int t = 0; t < flat->n; ++t) if (!grads[t]) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, grads, flat->n, st))) return rc;
+    if (sum_g4_dev) HIPCHK(hipMemsetAsync(sum_g4_dev, 0, sizeof(float), st));
+    if (flat->n_chunks)
+        hipLaunchKernelGGL(flat_gather_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks,
+                           (const void* const*)flat->d_ptrs, grad_dtype, g_flat, flat_dtype, m_flat, beta, sum_g4_dev);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
 
 int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, int clip, float max_avg_amp,
                             float max_elem_amp, void* stream) {
@@ -1641,6 +1673,7 @@ int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out
     return PSGDK_OK;
 }
 
+
 }  // extern "C"
 
 // ===================================================================================================================
@@ -1741,7 +1774,7 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
     float* sm = (float*)(L->work + L->sm_off);
     unsigned gb1, shm1;
     lra_geometry(L->N, L->r, 1, &gb1, &shm1);
-    HIPCHK(hipMemsetAsync(sm + LS_VTX2, 0, 32 * 4, st));
+    HIPCHK(hipMemsetAsync(sm + LS_HSQ, 0, (LS_UTY + 16 - LS_HSQ) * 4, st));
     LRA_T(L, {
         T* y = (T*)(L->work + L->y_off);
         for (int stage = 0; stage < 3; ++stage)
@@ -1749,6 +1782,13 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
                                (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
     });
     HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr) {
+    if (!lra || !dev_ptr) return PSGDK_ERR_INVALID;
+    if (!lra->work) return PSGDK_ERR_STATE;
+    *dev_ptr = (const float*)(lra->work + lra->sm_off) + LS_HSQ;
     return PSGDK_OK;
 }
 

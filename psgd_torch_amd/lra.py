@@ -20,7 +20,6 @@ from .engine import _on_device
 
 class _LraEngine:
     """One psgdk_lra object bound to (U, V, d, Luvd)."""
-    _cache = {}
 
     def __init__(self, UVd, Luvd3: torch.Tensor):
         U, V, d = UVd
@@ -36,7 +35,7 @@ class _LraEngine:
         wb = C.c_size_t()
         L.check(self.lib.psgdk_lra_work_bytes(self.h, C.byref(wb)), "lra_work_bytes")
         self.work = torch.zeros(wb.value, dtype=torch.uint8, device=d.device)
-        self.keep = (U, V, d, Luvd3)
+        self.keep = (U, V, None, Luvd3)       # (not d: the engine hangs on d itself, see _engine_for)
         self.device = d.device if d.device.index is not None else torch.device("cuda", torch.cuda.current_device())
         L.check(self.lib.psgdk_lra_bind(self.h, U.data_ptr() if self.r else None, V.data_ptr() if self.r else None, d.data_ptr(),
                                         Luvd3.data_ptr(), self.work.data_ptr()), "lra_bind")
@@ -50,7 +49,17 @@ class _LraEngine:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.keep[2].device).cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def owns_luvd(self, Luvd) -> bool:
+        base = self.keep[3]
+        return all(isinstance(x, torch.Tensor) and x.data_ptr() == base[i].data_ptr() for i, x in enumerate(Luvd))
+
+    def last_sumsq_ptr(self):
+        """Device word with the sum of squares of the last precond_grad output (the RMS clip reads it on the device)."""
+        p = C.c_void_p()
+        L.check(self.lib.psgdk_lra_last_sumsq(self.h, C.byref(p)), "lra_last_sumsq")
+        return p
 
     @_on_device
     def update_whiten(self, g, lr, betaL, damping, v_noise=None, seed=0, offset=0, update_u=True):
@@ -69,25 +78,37 @@ class _LraEngine:
         return out
 
 
-def _engine_for(UVd, Luvd) -> _LraEngine:
+def _engine_for(UVd, Luvd, rebind: bool = True) -> _LraEngine:
     """The reference passes (UVd, Luvd) lists of tensors around; the engine needs the three L scalars contiguous, so the
-    first call re-homes them into one 3-element fp32 tensor and makes Luvd[i] views of it (values preserved)."""
-    key = (UVd[2].data_ptr(), UVd[0].data_ptr() if UVd[0].numel() else 0)
-    eng = _LraEngine._cache.get(key)
+    first UPDATE call re-homes them into one 3-element fp32 tensor and makes Luvd[i] views of it (values preserved).
+    The engine lives ON the d tensor (an attribute), so it is freed with the tensors it is bound to -- no global cache."""
+    d = UVd[2]
+    eng = getattr(d, "_psgdk_lra", None)
+    key = (UVd[0].data_ptr() if UVd[0].numel() else 0, UVd[1].data_ptr() if UVd[1].numel() else 0)
+    if eng is not None and eng.key != key:
+        eng = None                        # U / V were replaced: bind afresh
+    if eng is not None and rebind and not eng.owns_luvd(Luvd):
+        eng = None                        # bound earlier by precond_grad_lra with placeholder scalars: take the caller's now
     if eng is None:
-        L3 = torch.stack([x.to(torch.float32).reshape(()) for x in Luvd]).to(UVd[2].device)
-        for i in range(3):
-            Luvd[i] = L3[i]
+        L3 = torch.stack([x.detach().to(torch.float32).reshape(()) for x in Luvd]).to(d.device)
+        if rebind:
+            for i in range(3):
+                Luvd[i] = L3[i]
         eng = _LraEngine(UVd, L3)
-        _LraEngine._cache[key] = eng
-        if len(_LraEngine._cache) > 64:
-            _LraEngine._cache.pop(next(iter(_LraEngine._cache)))
+        eng.key = key
+        d._psgdk_lra = eng
     return eng
+
+
+def _check_vec(g, d):
+    if g.device != d.device or g.dtype != d.dtype or g.numel() != d.numel():
+        raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"the vector must match d: {g.dtype}/{g.device}/{g.numel()} vs {d.dtype}/{d.device}/{d.numel()}")
 
 
 def update_precond_lra_whiten(UVd, Luvd, g, lr=0.1, betaL=0.9, damping=1e-9, *, v_noise=None, coin=None):
     """psgd.py:1066-1072 (-> 994-1052), in place.  Randomness: the Philox seed and the U-or-V coin (psgd.py:1035) are
     drawn from torch's global CPU generator unless `v_noise` / `coin` are given (parity tests)."""
+    _check_vec(g, UVd[2])
     eng = _engine_for(UVd, Luvd)
     seed = int(torch.randint(0, 2 ** 62, ()).item()) if v_noise is None else 0
     if coin is None:
@@ -96,91 +117,149 @@ def update_precond_lra_whiten(UVd, Luvd, g, lr=0.1, betaL=0.9, damping=1e-9, *, 
 
 
 def precond_grad_lra(UVd, g):
-    """psgd.py:1055-1063.  (Needs a prior update_precond_lra_whiten / LRAWhiten on the same UVd for the engine binding;
-    otherwise binds with zeroed Lipschitz scalars.)"""
-    key = (UVd[2].data_ptr(), UVd[0].data_ptr() if UVd[0].numel() else 0)
-    eng = _LraEngine._cache.get(key)
-    if eng is None:
-        eng = _engine_for(UVd, [torch.zeros([], dtype=torch.float32, device=UVd[2].device) for _ in range(3)])
+    """psgd.py:1055-1063.  (Before any update_precond_lra_whiten on this UVd the engine binds with placeholder Lipschitz
+    scalars; the first update re-binds with the caller's.)"""
+    _check_vec(g, UVd[2])
+    eng = getattr(UVd[2], "_psgdk_lra", None)
+    if eng is None or eng.key != (UVd[0].data_ptr() if UVd[0].numel() else 0, UVd[1].data_ptr() if UVd[1].numel() else 0):
+        eng = _engine_for(UVd, [torch.zeros([], dtype=torch.float32, device=UVd[2].device) for _ in range(3)], rebind=False)
     return eng.precond_grad(g)
 
 
+class _FlatVectors:
+    """psgdk_flat_*: all parameters of an LRAWhiten as ONE N-vector (concatenation in parameter order, psgd.py:1142)."""
+
+    def __init__(self, params, dtype, device):
+        self.lib = L.lib()
+        self.device = device if device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.numels = [int(p.numel()) for p in params]
+        self.n = len(params)
+        self.N = sum(self.numels)
+        offs, run = [], 0
+        for n in self.numels:
+            offs.append(run); run += n
+        self._h = C.c_void_p()
+        na, oa = (C.c_int64 * self.n)(*self.numels), (C.c_int64 * self.n)(*offs)
+        L.check(self.lib.psgdk_flat_create(C.byref(self._h), self.n, na, oa), "flat_create")
+        self.dtype = dtype
+        with torch.cuda.device(self.device):
+            self.g = torch.zeros(self.N, 1, dtype=dtype, device=self.device)          # the concatenated gradient
+            self.sum_g4 = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.psgdk_flat_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, tensors, what):
+        from .engine import _check_tensors
+        return _check_tensors(what, tensors, self.numels, self.device)
+
+    @_on_device
+    def gather(self, grads, m=None, beta=0.0, want_g4=False):
+        grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+        gdt = self._check(grads, "grads")
+        ga = L.ptr_array(grads)
+        self._keep = (ga, grads)
+        L.check(self.lib.psgdk_flat_gather(self._h, ga, L.dtype_code(gdt), self.g.data_ptr(), L.dtype_code(self.dtype),
+                                           m.data_ptr() if m is not None else None, float(beta),
+                                           self.sum_g4.data_ptr() if want_g4 else None, self._stream()), "flat_gather")
+
+    @_on_device
+    def apply_clipped(self, params, h, lr, hsq_ptr, max_avg_amp, max_elem_amp):
+        pdt = self._check(params, "params")
+        pa = L.ptr_array(params)
+        self._keep = (pa, list(params), h)
+        L.check(self.lib.psgdk_flat_apply_clipped(self._h, pa, L.dtype_code(pdt), h.data_ptr(), L.dtype_code(h.dtype), float(lr), hsq_ptr,
+                                                  self.N, float(max_avg_amp), float(max_elem_amp), self._stream()), "flat_apply_clipped")
+
+
 class LRAWhiten:
-    """psgd.py:1075-1190: same constructor arguments, mutable attributes and step(closure) protocol."""
+    """The closure-style LRA optimizer of the reference (psgd.py:1075-1190): same constructor arguments, the same attributes a
+    user may anneal between steps, the same step(closure) protocol -- built on the engine rather than on per-step tensor
+    algebra: the parameters are ONE resident N-vector layout (no per-step torch.cat), the momentum update rides the gather
+    pass, the RMS / element clipping and the scatter back into the parameters are one launch reading the device-side
+    ||h||^2 that the apply pass left behind (no host synchronisation anywhere in a step)."""
 
     def __init__(self, params_with_grad, rank_of_approximation: int = 10, preconditioner_init_scale: Optional[float] = None,
                  lr_params=0.001, lr_preconditioner=0.1, betaL=0.9, damping=1e-9, momentum=0.0, grad_clip_max_amps=(2.0, 10.0),
                  preconditioner_update_probability=1.0, update_preconditioner_first=True, whiten_grad=True):
-        self.lr_params = lr_params
-        self.lr_preconditioner = lr_preconditioner
-        self.betaL = betaL
-        self.damping = damping
+        # the reference's mutable members (psgd.py:1094-1103)
+        self.lr_params, self.lr_preconditioner, self.betaL, self.damping = lr_params, lr_preconditioner, betaL, damping
         self.momentum = momentum if (0 < momentum < 1) else 0.0
         self.grad_clip_max_amps = grad_clip_max_amps
         self.preconditioner_update_probability = preconditioner_update_probability
         self.update_preconditioner_first = update_preconditioner_first
-        params_with_grad = [params_with_grad, ] if isinstance(params_with_grad, torch.Tensor) else params_with_grad
-        self._params_with_grad = [p for p in params_with_grad if p.requires_grad]
-        dtype, device = self._params_with_grad[0].dtype, self._params_with_grad[0].device
-        self._param_sizes = [torch.numel(p) for p in self._params_with_grad]
-        self._param_cumsizes = torch.cumsum(torch.tensor(self._param_sizes), 0)
-        num_params = int(self._param_cumsizes[-1])
-        assert 0 <= rank_of_approximation < num_params, "Rank r should be in range [0, number of total parameters)"
-        assert rank_of_approximation <= 16, "the HIP LRA kernels hold r <= 16"
-        self._UVd = []
-        U = torch.randn(num_params, rank_of_approximation, dtype=dtype, device=device)      # psgd.py:1115-1118
-        self._UVd.append(U * (0.1 ** 0.5 / torch.linalg.vector_norm(U)) if rank_of_approximation else U)
-        V = torch.randn(num_params, rank_of_approximation, dtype=dtype, device=device)
-        self._UVd.append(V * (0.1 ** 0.5 / torch.linalg.vector_norm(V)) if rank_of_approximation else V)
+        plist = [params_with_grad] if isinstance(params_with_grad, torch.Tensor) else list(params_with_grad)
+        self._params_with_grad = [p for p in plist if p.requires_grad]
+        p0 = self._params_with_grad[0]
+        self._vec = _FlatVectors(self._params_with_grad, p0.dtype, p0.device)
+        N, r = self._vec.N, int(rank_of_approximation)
+        assert 0 <= r < N, "Rank r should be in range [0, number of total parameters)"
+        if r > 16:
+            raise NotImplementedError("the HIP LRA kernels hold rank <= 16 (psgdk_lra_create: PSGDK_ERR_UNSUPPORTED)")
+        dev, dt = self._vec.device, p0.dtype
+
+        def unit_scaled():                                                   # psgd.py:1115-1118
+            x = torch.randn(N, r, dtype=dt, device=dev)
+            return x * (0.1 ** 0.5 / torch.linalg.vector_norm(x)) if r else x
+        self._UVd = [unit_scaled(), unit_scaled()]
+        self._init_scale = preconditioner_init_scale
         if preconditioner_init_scale is None:
             print("FYI: Will set the preconditioner initial scale on the fly. Recommend to set it manually.")
         else:
-            self._UVd.append(torch.ones(num_params, 1, dtype=dtype, device=device) * preconditioner_init_scale)
-        self._Luvd = [torch.zeros([], dtype=torch.float32, device=device) for _ in range(3)]
+            self._UVd.append(torch.full((N, 1), float(preconditioner_init_scale), dtype=dt, device=dev))
+        self._Luvd = [torch.zeros([], dtype=torch.float32, device=dev) for _ in range(3)]
         self._m, self._counter_m = None, 0
         self._whiten_grad = whiten_grad
         if not whiten_grad:
             assert self.momentum > 0, "Cannot whiten momentum if the momentum setting is invalid."
-        # test hooks: replay recorded draws
+        # hooks for tests that replay the reference's recorded draws
         self._uniform = lambda: float(torch.rand([]))
         self._v_noise = None
+
+    def _update(self, target):
+        update_precond_lra_whiten(self._UVd, self._Luvd, target, lr=self.lr_preconditioner, betaL=self.betaL, damping=self.damping,
+                                  v_noise=self._v_noise() if self._v_noise is not None else None, coin=self._uniform())
 
     @torch.no_grad()
     def step(self, closure):
         with torch.enable_grad():
-            closure_returns = closure()
-            loss = closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
+            out = closure()
+            loss = out if isinstance(out, torch.Tensor) else out[0]
             grads = torch.autograd.grad(loss, self._params_with_grad)
-        grad = torch.cat([torch.reshape(g, [-1, 1]) for g in grads])                          # psgd.py:1142
-        if len(self._UVd) < 3:                                                                  # psgd.py:1144-1145
-            self._UVd.append((torch.mean(grad ** 4) + self.damping ** 4) ** (-1 / 8) * torch.ones_like(grad))
-        if self.momentum > 0:                                                                   # psgd.py:1147-1155
+        vec = self._vec
+        use_m = self.momentum > 0
+        if use_m:                                                            # psgd.py:1147-1153
             beta = min(self._counter_m / (1 + self._counter_m), self.momentum)
             self._counter_m += 1
             if self._m is None:
-                self._m = torch.zeros_like(grad)
-            self._m.mul_(beta).add_(grad, alpha=1 - beta)
-        else:
-            self._m, self._counter_m = None, 0
-        if self._uniform() < self.preconditioner_update_probability:                            # psgd.py:1157-1160
+                self._m = torch.zeros_like(vec.g)
+        else:                                                                # psgd.py:1154-1155
+            beta, self._m, self._counter_m = 0.0, None, 0
+        need_d = len(self._UVd) < 3
+        vec.gather(grads, m=self._m, beta=beta, want_g4=need_d)              # g (and m) as one N-vector; sum g^4 if d is unset
+        if need_d:                                                           # psgd.py:1144-1145, on the device
+            scale = (vec.sum_g4 / vec.N + self.damping ** 4) ** (-1 / 8)
+            self._UVd.append(scale.to(vec.g.dtype) * torch.ones_like(vec.g))
+        if self._uniform() < self.preconditioner_update_probability:         # psgd.py:1157-1160
             first, last = self.update_preconditioner_first, not self.update_preconditioner_first
         else:
             first, last = False, False
-        target = grad if self._whiten_grad else self._m
-
-        def do_update():
-            vn = self._v_noise() if self._v_noise is not None else None
-            update_precond_lra_whiten(self._UVd, self._Luvd, target, lr=self.lr_preconditioner, betaL=self.betaL,
-                                      damping=self.damping, v_noise=vn, coin=self._uniform())
+        target = vec.g if self._whiten_grad else self._m
         if first:
-            do_update()
-        pre_grad = precond_grad_lra(self._UVd, self._m if self.momentum > 0 else grad)          # psgd.py:1168-1171
+            self._update(target)
+        h = precond_grad_lra(self._UVd, self._m if use_m else vec.g)         # psgd.py:1168-1171
         if last:
-            do_update()
-        max_avg_amp, max_element_amp = self.grad_clip_max_amps                                  # psgd.py:1179-1183
-        avg_amp = torch.sqrt(torch.mean(pre_grad * pre_grad))
-        pre_grad = pre_grad * torch.clamp(max_avg_amp / avg_amp, max=1.0)                       # branch-free: no host sync
-        pre_grad.clamp_(min=-max_element_amp, max=max_element_amp)
-        for (param, i, j) in zip(self._params_with_grad, self._param_sizes, self._param_cumsizes):
-            param.subtract_(pre_grad[j - i:j].view_as(param), alpha=self.lr_params)
-        return closure_returns
+            self._update(target)
+        eng = self._UVd[2]._psgdk_lra
+        max_avg_amp, max_element_amp = self.grad_clip_max_amps               # psgd.py:1179-1187, one launch
+        vec.apply_clipped(self._params_with_grad, h, self.lr_params, eng.last_sumsq_ptr(), max_avg_amp, max_element_amp)
+        return out
