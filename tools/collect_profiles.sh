@@ -21,3 +21,15 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- python $R/bench.py 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only > /dev/null 2> $out/pmc_write.err
 python $R/tools/pmc_traffic.py $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) > $out/pmc_traffic.json
 ls -la $out
+# SQ counters, two passes of four (MFMA pipe busy + LDS conflicts; where the wave cycles went) -- counters only with --kernel-trace
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p_sq1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only > /dev/null 2> $out/pmc_sq1.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d /tmp/p_sq2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only > /dev/null 2> $out/pmc_sq2.err
+python $R/tools/pmc_sq.py $(find /tmp/p_sq1 -name "*.db" | head -1) > $out/pmc_sq_mfma.json
+python $R/tools/pmc_sq.py $(find /tmp/p_sq2 -name "*.db" | head -1) > $out/pmc_sq_waits.json
+# GPT-2-medium under rocprofv3 (the 8-GPU configuration's shapes on one GPU)
+rocprofv3 --kernel-trace --stats -d /tmp/p_med -- python $R/bench.py --config gpt2-medium --steps 8 --warmup 3 --no-cpu-baseline --no-apply-only > $out/bench_gpt2-medium_under_rocprof.json 2> $out/rocprof_med.err
+dbm=$(find /tmp/p_med -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $dbm > $out/gpt2-medium_kernel_stats.md
+python $R/tools/rocpd_sequence.py $dbm accumulate_kernel -3 > $out/gpt2-medium_step_sequence.md
+python $R/tools/parity_report.py > $out/parity_report.md 2> $out/parity_report.err
+ls -la $out
