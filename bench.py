@@ -122,7 +122,7 @@ def bench_lra(args):
     from psgd_torch_amd import lra
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    N, r = 86543080, 10
+    N, r = 86543080, args.lra_rank
     gen = torch.Generator(device=dev).manual_seed(0)
     U = torch.randn(N, r, device=dev, generator=gen); U *= 0.1 ** 0.5 / torch.linalg.vector_norm(U)
     V = torch.randn(N, r, device=dev, generator=gen); V *= 0.1 ** 0.5 / torch.linalg.vector_norm(V)
@@ -145,7 +145,8 @@ def bench_lra(args):
     out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "fp32", "data": "synthetic",
-           "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra"},
+           "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra",
+                      "rank": r},
            "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": None, "algorithmic_gb_per_step": bytes_alg / 1e9}}
     print(json.dumps(out), flush=True)
@@ -201,6 +202,7 @@ def main():
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank code path with --same-device)")
+    ap.add_argument("--lra-rank", type=int, default=10, help="vit-b-lra only: rank of the approximation (BASELINE config 4: 10)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--parallelism", default="auto", choices=["auto", "sharded", "replicated"],
                     help="N > 1: per-parameter state sharding + one all-gather per step, or replicas (the reference's DDP "

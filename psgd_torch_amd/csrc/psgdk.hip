@@ -1688,13 +1688,15 @@ struct psgdk_lra {
 
 extern "C" {
 
+static int lra_sm_total(int tpr) { return tpr == 1 ? LraCfg<1>::TOTAL : (tpr == 2 ? LraCfg<2>::TOTAL : LraCfg<4>::TOTAL); }
+
 int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype) {
     if (!out || N <= 0 || r < 0 || (r > 0 && r >= N) || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
-    if (r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;        // valid upstream (any rank); the kernels hold r <= 16
+    if (r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;        // valid upstream (any rank); the kernels hold r <= 64
     psgdk_lra* L = new psgdk_lra();
     L->N = N; L->r = r; L->dtype = dtype; L->esz = dtype == PSGDK_BF16 ? 2 : 4;
     size_t wo = 0;
-    L->sm_off = wo; wo += align256((size_t)LS_TOTAL * 4);
+    L->sm_off = wo; wo += align256((size_t)lra_sm_total(lra_tpr_of_rank(r)) * 4);
     const size_t nb = align256((size_t)N * L->esz);
     L->v_off = wo; wo += nb; L->h_off = wo; wo += nb; L->qh_off = wo; wo += nb; L->iq_off = wo; wo += nb;
     L->diff_off = wo; wo += nb; L->y_off = wo; wo += nb;
@@ -1717,14 +1719,20 @@ int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void*
     return PSGDK_OK;
 }
 
-#define LRA_T(L, CALL) do { if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; CALL; } else { typedef float T; CALL; } } while (0)
+// element type x rank class (threads per row: 1, 2, 4 for ranks up to 16, 32, 64)
+#define LRA_TPR_(tpr_, ...) do { if ((tpr_) == 1) { constexpr int TPR = 1; __VA_ARGS__; } else if ((tpr_) == 2) { constexpr int TPR = 2; __VA_ARGS__; } \
+                                 else { constexpr int TPR = 4; __VA_ARGS__; } } while (0)
+#define LRA_T(L, ...) do { const int tpr_ = lra_tpr_of_rank((L)->r);                                        \
+                           if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; LRA_TPR_(tpr_, __VA_ARGS__); }  \
+                           else { typedef float T; LRA_TPR_(tpr_, __VA_ARGS__); } } while (0)
 
-// launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of 256 x r floats, and as many workgroups as are
-// resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
-static void lra_geometry(int64_t N, int r, int mats, unsigned* grid, unsigned* shm) {
-    const unsigned bytes = (unsigned)std::max(16, mats * LRA_ROWS * r * 4);
-    const unsigned per_cu = std::max(1u, std::min(8u, (160u * 1024u) / (bytes + 1024u)));
-    const int64_t blocks = (N + LRA_ROWS - 1) / LRA_ROWS;
+// launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of (256 / tpr) x r floats (+ `fixed` bytes of
+// static LDS), and as many workgroups as are resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
+static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm) {
+    const int rows = LRA_ROWS / lra_tpr_of_rank(r);
+    const unsigned bytes = (unsigned)std::max(16, mats * rows * r * 4);
+    const unsigned per_cu = std::max(1u, std::min(8u, (160u * 1024u) / (bytes + fixed + 1024u)));
+    const int64_t blocks = (N + rows - 1) / rows;
     *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * (int64_t)per_cu));
     *shm = bytes;
 }
@@ -1738,28 +1746,33 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
     hipStream_t st = (hipStream_t)stream;
     float* sm = (float*)(L->work + L->sm_off);
     const int64_t N = L->N; const int r = L->r;
-    const unsigned gb = (unsigned)std::min<int64_t>((N + LRA_ROWS - 1) / LRA_ROWS, 2048);
-    unsigned gb1, gb2, shm1, shm2;
-    lra_geometry(N, r, 1, &gb1, &shm1); lra_geometry(N, r, 2, &gb2, &shm2);
-    HIPCHK(hipMemsetAsync(sm, 0, (size_t)LS_TOTAL * 4, st));
+    const int tpr = lra_tpr_of_rank(r), rm = 16 * tpr;
+    const unsigned gb = (unsigned)std::min<int64_t>((N + 255) / 256, 2048);
+    unsigned gb1, gb2, gbr, shm1, shm2, shmr;
+    lra_geometry(N, r, 1, 0, &gb1, &shm1); lra_geometry(N, r, 2, 0, &gb2, &shm2);
+    lra_geometry(N, r, 2, 2u * rm * rm * 4u, &gbr, &shmr);                       // the rotation keeps M_u, M_v in LDS as well
+    const unsigned shm_s1 = 7u * rm * rm * 4u;
+    HIPCHK(hipMemsetAsync(sm, 0, (size_t)lra_sm_total(tpr) * 4, st));
     LRA_T(L, {
         T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
         T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
         hipLaunchKernelGGL(lra_prep_kernel<T>, dim3(gb), dim3(256), 0, st, (const T*)g, (const T*)v_noise, v, h, N, damping, seed, offset);
         if (r > 0) {
-            hipLaunchKernelGGL(lra_gram_kernel<T>, dim3(gb2), dim3(256), shm2, st, (const T*)U, (const T*)V, N, r, sm);
-            hipLaunchKernelGGL(lra_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, r);
+            hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
+            if (shm_s1 > 64u * 1024u)
+                HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
+            hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
         }
-        hipLaunchKernelGGL(lra_rotate_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
-        hipLaunchKernelGGL(lra_small2_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL(lra_pass3_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+        hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+        hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+        hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
                            (const T*)h, Qh, iq, N, r, sm);
-        hipLaunchKernelGGL(lra_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL(lra_pass4_kernel<T>, dim3(gb2), dim3(LRA_ROWS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
+        hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+        hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
                            (const T*)h, (const T*)Qh, (const T*)iq, diff, N, r, sm);
-        hipLaunchKernelGGL(lra_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
-        hipLaunchKernelGGL(lra_pass5_kernel<T>, dim3(gb1), dim3(LRA_ROWS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+        hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
+        hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                            N, r, update_u ? 1 : 0, (const float*)sm);
     });
     HIPCHK(hipGetLastError());
@@ -1773,12 +1786,12 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
     hipStream_t st = (hipStream_t)stream;
     float* sm = (float*)(L->work + L->sm_off);
     unsigned gb1, shm1;
-    lra_geometry(L->N, L->r, 1, &gb1, &shm1);
-    HIPCHK(hipMemsetAsync(sm + LS_HSQ, 0, (LS_UTY + 16 - LS_HSQ) * 4, st));
+    lra_geometry(L->N, L->r, 1, 0, &gb1, &shm1);
     LRA_T(L, {
+        HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
         T* y = (T*)(L->work + L->y_off);
         for (int stage = 0; stage < 3; ++stage)
-            hipLaunchKernelGGL(lra_apply_kernel<T>, dim3(gb1), dim3(LRA_ROWS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+            hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                                (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
     });
     HIPCHK(hipGetLastError());
@@ -1788,7 +1801,8 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
 int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr) {
     if (!lra || !dev_ptr) return PSGDK_ERR_INVALID;
     if (!lra->work) return PSGDK_ERR_STATE;
-    *dev_ptr = (const float*)(lra->work + lra->sm_off) + LS_HSQ;
+    const int tpr = lra_tpr_of_rank(lra->r);
+    *dev_ptr = (const float*)(lra->work + lra->sm_off) + (tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ));
     return PSGDK_OK;
 }
 

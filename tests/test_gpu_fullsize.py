@@ -258,6 +258,13 @@ def test_lra_vit_b_scale_n2e7_r10():
     _lra_case(20_000_003, 10)          # ragged N (not a multiple of any tile)
 
 
+@pytest.mark.parametrize("r", [24, 32, 48, 64])
+def test_lra_wide_ranks_n3e6(r):
+    """The two wider rank classes (two / four threads per row: 128- / 64-row blocks, tiled Grams, wave-parallel LU) at a size
+    where every workgroup loops several times, ragged N; fp32 vs the fp64 oracle (psgd.py:994-1072)."""
+    _lra_case(3_000_017, r, steps=2, seed=r)
+
+
 def test_lra_vit_b_true_n_r10():
     """The true ViT-B/16 N = 86,543,080 (misc/vit.py ViT(224,16,1000,768,12,12,3072)); needs ~25 GB of host memory for
     the fp64 oracle."""

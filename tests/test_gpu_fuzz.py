@@ -148,16 +148,17 @@ def test_random_kwns4_configuration_matches_oracle_loop(seed):
         assert relerr(p.detach(), q) <= 1e-4, (seed, shapes, kw, i, relerr(p.detach(), q))
 
 
-L_CASES = int(os.environ.get("PSGDK_FUZZ_LRA", "12"))
+L_CASES = int(os.environ.get("PSGDK_FUZZ_LRA", "24"))
 
 
 @pytest.mark.parametrize("seed", list(range(L_CASES)))
 def test_random_lra_case_matches_oracle(seed):
-    """LRA update + apply with random N (ragged against the 256-row blocks), rank 0..16, both update branches; fp32."""
+    """LRA update + apply with random N (ragged against the 256- / 128- / 64-row blocks of the three rank classes), rank 0..64,
+    both update branches; fp32."""
     from psgd_torch_amd import lra
     rnd = random.Random(9000 + seed)
-    N = rnd.choice([1, 2, 17, 255, 256, 257, 511, 1000, 2049, 5000])
-    r = min(rnd.choice([0, 1, 2, 5, 10, 16]), max(N - 1, 0))
+    N = rnd.choice([1, 2, 17, 63, 65, 127, 129, 255, 256, 257, 511, 1000, 2049, 5000])
+    r = min(rnd.choice([0, 1, 2, 5, 10, 16, 17, 24, 32, 33, 47, 64]), max(N - 1, 0))
     gen = torch.Generator().manual_seed(9100 + seed)
     U = torch.randn(N, r, generator=gen); V = torch.randn(N, r, generator=gen)
     if r:

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", golden_names("lra_"))
+@pytest.mark.parametrize("name", golden_names("lra_") + golden_names("lrabig_"))      # lrabig_: rank 32 (two threads per row)
 def test_lra_functional_vs_golden(name):
     from psgd_torch_amd import lra
     z = load(name)
