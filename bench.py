@@ -118,7 +118,8 @@ def cpu_baseline(seconds_budget=9.0):
 def bench_lra(args):
     """BASELINE config 4: ViT-B/16 parameter count (N = 86,543,080), LRA rank 10, fp32: update_precond_lra_whiten +
     precond_grad_lra per step (psgd.py:1066, 1055).  HBM-bound: algorithmic bytes = 9 matrix reads + 3 matrix writes
-    (update) + 3 matrix reads (apply), matrix pass = N*r*4 bytes, plus ~24 N-vector passes."""
+    (update) + 3 matrix reads (apply), matrix pass = N*r*4 bytes, plus 18 + 3 N-vector passes (the kernels
+    actually move 30 vector passes, DESIGN.md section 3 has the per-pass table)."""
     from psgd_torch_amd import lra
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
@@ -141,7 +142,7 @@ def bench_lra(args):
         one_step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
-    bytes_alg = (12 + 3) * N * r * 4 + 24 * N * 4
+    bytes_alg = (12 + 3) * N * r * 4 + (18 + 3) * N * 4        # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
     out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "fp32", "data": "synthetic",
@@ -172,17 +173,47 @@ def bench_eq(args):
         eng.apply_update(params, 2e-4, 0.0, 2.0, 10.0)
     for i in range(args.warmup):
         one_step(i)
+    eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    sample = 4 if args.steps >= 8 else 1            # (event pairs around the GEMM launches on every 4th step only: see main())
+    prof_steps = 0
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        on = (not args.no_roofline) and (i % sample == sample - 1)
+        prof_steps += int(on)
+        eng.profile_enable(on)
         one_step(args.warmup + i)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
+    gemm_ms, gemm_launches = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    # FLOPs of the products that run in the grouped GEMM kernel, per dense factor d of a tensor of N elements (psgd.py:278-327):
+    # A = (kron Q) Hvp 2Nd, the two mode Grams 2 x 2Nd, Q -= mu triu(.) Q 2d^3, apply: P = Q^T Q 2d^3 + h = (kron P) g 2Nd.
+    # `dense`: as the reference's einsums count them (they do not exploit the triangular Q); `executed`: with the zero halves of
+    # triangular operands skipped (Q in A: half of K; triu(.) Q: a third of the d^3 cube) -- the roofline uses the SMALLER one.
+    dense = executed = 0.0
+    for shp in shapes:
+        N = math.prod(shp)
+        for d in shp:
+            if d <= 1 or d * d > N:
+                continue
+            dense += 8.0 * N * d + 4.0 * d ** 3
+            executed += 7.0 * N * d + (2.0 / 3.0 + 2.0) * d ** 3
     out = {"metric": "psgd_kron_step_throughput", "value": nparam / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"GPT-2-small parameter shapes ({nparam} params), dQ=EQ (triangular Q, fp32 right solves), "
                                   "momentum 0.9, update probability 1, max_skew 1", "preconditioner_dtype": "bf16"}}
+    if prof_steps and gemm_launches:
+        per_step_ms = gemm_ms / prof_steps
+        ach = executed / (per_step_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_nt_pipe_kernel <bf16> (all grouped-GEMM launches of the EQ step; "
+                                                      "the triangular solves run in eq_trsm_bf16_kernel and are not part of it)",
+                           "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                           "launches_per_step": gemm_launches / prof_steps, "avg_launch_us": gemm_ms * 1e3 / gemm_launches,
+                           "algorithmic_gflop_per_launch": executed / 1e9 / (gemm_launches / prof_steps),
+                           "gemm_ms_per_step": per_step_ms, "gflop_dense_as_reference": dense / 1e9, "gflop_executed": executed / 1e9}
     print(json.dumps(out), flush=True)
 
 

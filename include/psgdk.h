@@ -283,9 +283,17 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
 
 /* X = Y * inv(U) for an upper-triangular U [d x d, row stride ld_u] and Y [rows x d, row stride ld] (the fp32 right
  * solve of psgd.py:288-293), same kernel the EQ update uses; dp = roundup(d, 64) must equal ld_u and ld, buffers padded
- * with zeros to multiples of 64 in both extents.  out_nat [rows_p x dp] and/or out_t [dp x rows_p] (either may be NULL). */
-int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d,
+ * with zeros to multiples of 64 in both extents.  out_nat [rows_p x dp] and/or out_t [dp x rows_p] (either may be NULL).
+ * Ut: NULL -> the fp32-matrix-core kernel (every dtype); U^T [dp x dp] -> the bf16 kernel the EQ update uses for bf16 state
+ * (panel resident in LDS, updates on the bf16 matrix cores; dtype must be PSGDK_BF16, dp <= 1088). */
+int psgdk_test_trsm_right(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int dtype, int rows, int d,
                           void* stream);
+/* Timing of the solve kernels alone (bf16; tools/trsm_bench.py): average of `iters` launches between two events.  Ut as above;
+ * dbg (bf16 LDS-panel kernel only): 1 = without the update loop, 2 = without the diagonal step, 4 = without the stores,
+ * 8 = 64-row panels (one workgroup per CU) instead of 32-row ones, 16 = the first panel's thread 0 writes shader-clock stamps of
+ * its phase boundaries (2 + 4 per 64-column block + 2, int64) into `stamps` (device memory, >= 1 KiB). */
+int psgdk_test_trsm_bench(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int rows, int d, int iters, int dbg,
+                          float* avg_ms, void* stamps, void* stream);
 
 /* Host-only: builds the tile table the grouped GEMM would use for `n` dense problems C[M,N] (K each; sym[i] != 0: upper
  * tiles only) on the 128x128 (big = 0) or 256x256 (big = 1) tiling and reports, per XCD queue, its tile count and its summed

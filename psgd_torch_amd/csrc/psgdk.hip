@@ -719,7 +719,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             GemmProblem q{};
             q.A = W + F.r_off; q.B = S + F.qt_off; q.C = W + F.qn_off; q.Ct = W + F.qtn_off;
             q.M = q.N = q.K = F.dp; q.lda = q.ldb = q.ldc = q.ldct = q.ldq = F.dp; q.alpha = 1.f;
-            q.flags = GF_QUPD; q.Qold = S + F.q_off; q.mu_dev = sc + DS_MU; q.c = 0.f;
+            // (both operands triangular: triu(.) is zero left of the diagonal, Q^T right of it)
+            q.flags = GF_QUPD | GF_KBAND_A_UP | GF_KBAND_B_LO; q.Qold = S + F.q_off; q.mu_dev = sc + DS_MU; q.c = 0.f;
             P->e_qupd.probs.push_back(q);
         }
         for (int t = 0; t < P->n_tensors; ++t) {
@@ -730,9 +731,9 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             // A = (row factor) Hvp Qc^T: first the column side
             GemmProblem a{};
             a.A = W + D.x_off; a.B = S + Fc.q_off; a.M = D.Rp; a.N = D.Cp; a.K = D.Cp; a.lda = D.Cp; a.ldb = Fc.dp; a.alpha = 1.f;
-            a.flags = GF_TMAJOR; a.ldct = D.Rp;
+            a.flags = GF_TMAJOR | GF_KBAND_B_UP; a.ldct = D.Rp;          // Q upper triangular: Q[n][k] = 0 for k < n
             TrsmJob j{};
-            j.in = W + D.v_off; j.ld_in = D.Cp; j.U = S + Fc.q_off; j.uinv = (const float*)(W + Fc.uinv_off);
+            j.in = W + D.v_off; j.ld_in = D.Cp; j.U = S + Fc.q_off; j.Ut = S + Fc.qt_off; j.uinv = (const float*)(W + Fc.uinv_off);
             j.rows = D.R; j.dp = Fc.dp;
             if (D.kind == TK_M1) {
                 a.Ct = W + D.pgt_off;
@@ -746,11 +747,12 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 GemmProblem b{};
                 b.A = S + Fr.q_off; b.B = W + D.tt_off; b.M = D.Rp; b.N = D.Cp; b.K = D.Rp; b.lda = Fr.dp; b.ldb = D.Rp; b.alpha = 1.f;
                 b.C = W + D.pg_off; b.ldc = D.Cp; b.Ct = W + D.pgt_off; b.ldct = D.Rp;
+                b.flags = GF_KBAND_A_UP;
                 P->e_a2.probs.push_back(b);
                 // V Qc^{-1} -> (.)^T in tt (free again after the second product), then (.)^T Qr^{-1} = B^T, and B
                 j.out_t = W + D.tt_off; j.ld_t = D.Rp;
                 TrsmJob k{};
-                k.in = W + D.tt_off; k.ld_in = D.Rp; k.U = S + Fr.q_off; k.uinv = (const float*)(W + Fr.uinv_off);
+                k.in = W + D.tt_off; k.ld_in = D.Rp; k.U = S + Fr.q_off; k.Ut = S + Fr.qt_off; k.uinv = (const float*)(W + Fr.uinv_off);
                 k.rows = D.C; k.dp = Fr.dp;
                 k.out_nat = W + D.bt_off; k.ld_nat = D.Rp; k.out_t = W + D.bb_off; k.ld_t = D.Cp;
                 for (int pnl = 0; pnl < D.Cp / 64; ++pnl) ttiles[1].push_back(TrsmTile{(int)jobs[1].size(), pnl});
@@ -1168,6 +1170,33 @@ int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL
     return update_whiten_family(plan, PSGDK_GEOM_QEP, source, lr, betaL, damping, noise, seed, offset, nullptr, stream);
 }
 
+// the bf16 solve (panel resident in LDS, updates on the bf16 matrix cores); PSGDK_TRSM=f32 keeps the fp32-core kernel (A/B runs)
+static bool trsm_f32_cores() {
+    static const bool v = [] { const char* e = std::getenv("PSGDK_TRSM"); return e && std::string(e) == "f32"; }();
+    return v;
+}
+// rows per panel of the bf16 solve: 32 (default: two workgroups per CU) or 64 (PSGDK_TRSM_ROWS=64; A/B runs)
+static int trsm_rows() {
+    static const int v = [] { const char* e = std::getenv("PSGDK_TRSM_ROWS"); return (e && std::atoi(e) == 64) ? 64 : 32; }();
+    return v;
+}
+static int launch_trsm_bf16(const TrsmJob* jobs, const TrsmTile* tiles, unsigned n_tiles, int max_dp, hipStream_t st, int dbg = 0,
+                            int rows = 0) {
+    if (!rows) rows = trsm_rows();
+    const unsigned shm = (unsigned)rows * (unsigned)(max_dp + 8) * 2u + 64u * (unsigned)(rows + 4) * 4u;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)eq_trsm_bf16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)eq_trsm_bf16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const unsigned n_pan = n_tiles * (64u / (unsigned)rows);
+    const unsigned grid = ((n_pan + 7) / 8) * 8;
+    if (rows == 64) hipLaunchKernelGGL(eq_trsm_bf16_kernel<64>, dim3(grid), dim3(256), shm, st, jobs, tiles, (int)n_tiles, dbg);
+    else hipLaunchKernelGGL(eq_trsm_bf16_kernel<32>, dim3(grid), dim3(256), shm, st, jobs, tiles, (int)n_tiles, dbg);
+    return PSGDK_OK;
+}
+
 int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL, float damping,
                             const psgdk_noise* noise, uint64_t seed, uint64_t offset,
                             const uint8_t* balance_mask, void* stream) {
@@ -1204,8 +1233,13 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     if (P->n_uinv)
         DISPATCH_T(P, hipLaunchKernelGGL(eq_uinv_kernel<T>, dim3((unsigned)(P->max_dp / 64), P->n_uinv), dim3(64), 0, st, P->d_uinv));
     for (int k = 0; k < 2; ++k)
-        if (P->n_trsm_tiles[k])
-            DISPATCH_T(P, hipLaunchKernelGGL(eq_trsm_kernel<T>, dim3(P->n_trsm_tiles[k]), dim3(256), 0, st, P->d_trsm[k], P->d_trsm_tiles[k]));
+        if (P->n_trsm_tiles[k]) {
+            if (P->dtype == PSGDK_BF16 && P->max_dp <= EQ_TRSM_BF16_MAX_DP && !trsm_f32_cores()) {
+                const int rc = launch_trsm_bf16(P->d_trsm[k], P->d_trsm_tiles[k], P->n_trsm_tiles[k], P->max_dp, st);
+                if (rc) return rc;
+            } else
+                DISPATCH_T(P, hipLaunchKernelGGL(eq_trsm_kernel<T>, dim3(P->n_trsm_tiles[k]), dim3(256), 0, st, P->d_trsm[k], P->d_trsm_tiles[k]));
+        }
     if (P->n_tiles_diag)
         DISPATCH_T(P, hipLaunchKernelGGL(eq_diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
                                          P->d_tiles_diag, P->state, P->work));
@@ -1646,7 +1680,9 @@ int psgdk_test_tile_queues(int n, const int32_t* M, const int32_t* N, const int3
     return PSGDK_OK;
 }
 
-int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out_t, int dtype, int rows, int d, void* stream) {
+int psgdk_test_trsm_right(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int dtype, int rows, int d,
+                          void* stream) {
+    if (Ut && (dtype != PSGDK_BF16 || round_up64(d) > EQ_TRSM_BF16_MAX_DP)) return PSGDK_ERR_INVALID;
     if (!Y || !U || (!out_nat && !out_t) || rows <= 0 || d <= 0 || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int dp = (int)round_up64(d), rp = (int)round_up64(rows);
@@ -1654,7 +1690,7 @@ int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out
     HIPCHK(hipMalloc((void**)&uinv, (size_t)dp * 64 * 4));
     std::vector<UinvJob> uj = {UinvJob{U, uinv, d, dp}};
     TrsmJob j{};
-    j.in = Y; j.ld_in = dp; j.U = U; j.uinv = uinv; j.out_nat = out_nat; j.ld_nat = dp; j.out_t = out_t; j.ld_t = rp; j.rows = rows; j.dp = dp;
+    j.in = Y; j.ld_in = dp; j.U = U; j.Ut = Ut; j.uinv = uinv; j.out_nat = out_nat; j.ld_nat = dp; j.out_t = out_t; j.ld_t = rp; j.rows = rows; j.dp = dp;
     std::vector<TrsmJob> jobs = {j};
     std::vector<TrsmTile> tiles;
     for (int p = 0; p < rp / 64; ++p) tiles.push_back(TrsmTile{0, p});
@@ -1662,13 +1698,50 @@ int psgdk_test_trsm_right(const void* Y, const void* U, void* out_nat, void* out
     if ((rc = upload(&dj, uj)) || (rc = upload(&tj, jobs)) || (rc = upload(&tt, tiles))) return rc;
     if (dtype == PSGDK_BF16) {
         hipLaunchKernelGGL(eq_uinv_kernel<bf16_t>, dim3(dp / 64, 1), dim3(64), 0, st, dj);
-        hipLaunchKernelGGL(eq_trsm_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
+        if (Ut) { if ((rc = launch_trsm_bf16(tj, tt, (unsigned)tiles.size(), dp, st))) return rc; }
+        else hipLaunchKernelGGL(eq_trsm_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
     } else {
         hipLaunchKernelGGL(eq_uinv_kernel<float>, dim3(dp / 64, 1), dim3(64), 0, st, dj);
         hipLaunchKernelGGL(eq_trsm_kernel<float>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(uinv); (void)hipFree(dj); (void)hipFree(tj); (void)hipFree(tt);
+    return PSGDK_OK;
+}
+
+// timing of the two solve kernels alone (tools/trsm_bench.py): `iters` launches between two events; dbg: see eq_trsm_bf16_kernel
+int psgdk_test_trsm_bench(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int rows, int d, int iters, int dbg,
+                          float* avg_ms, void* stamps, void* stream) {
+    if (!Y || !U || (!out_nat && !out_t) || rows <= 0 || d <= 0 || iters <= 0 || !avg_ms) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int dp = (int)round_up64(d), rp = (int)round_up64(rows);
+    if (Ut && dp > EQ_TRSM_BF16_MAX_DP) return PSGDK_ERR_INVALID;
+    float* uinv = nullptr; UinvJob* dj = nullptr; TrsmJob* tj = nullptr; TrsmTile* tt = nullptr;
+    HIPCHK(hipMalloc((void**)&uinv, (size_t)dp * 64 * 4));
+    std::vector<UinvJob> uj = {UinvJob{U, uinv, d, dp}};
+    TrsmJob j{};
+    j.in = Y; j.ld_in = dp; j.U = U; j.Ut = Ut; j.uinv = uinv; j.out_nat = out_nat; j.ld_nat = dp; j.out_t = out_t; j.ld_t = rp; j.rows = rows; j.dp = dp;
+    if (dbg & 16) { if (!stamps) return PSGDK_ERR_INVALID; j.row_ss = (float*)stamps; }
+    std::vector<TrsmJob> jobs = {j};
+    std::vector<TrsmTile> tiles;
+    for (int p = 0; p < rp / 64; ++p) tiles.push_back(TrsmTile{0, p});
+    int rc;
+    if ((rc = upload(&dj, uj)) || (rc = upload(&tj, jobs)) || (rc = upload(&tt, tiles))) return rc;
+    hipLaunchKernelGGL(eq_uinv_kernel<bf16_t>, dim3(dp / 64, 1), dim3(64), 0, st, dj);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int it = -2; it < iters; ++it) {
+        if (it == 0) HIPCHK(hipEventRecord(e0, st));
+        if (Ut) { if ((rc = launch_trsm_bf16(tj, tt, (unsigned)tiles.size(), dp, st, dbg & 23, (dbg & 8) ? 64 : 32))) return rc; }
+        else hipLaunchKernelGGL(eq_trsm_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(uinv); (void)hipFree(dj); (void)hipFree(tj); (void)hipFree(tt);
     return PSGDK_OK;
 }
