@@ -776,13 +776,20 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     // (M = 64) and the EQ stages stay on the small tiling.  Both tilings accumulate K in the same order: same bits.
     for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1],
                      &P->g_app_b}) {
-        int64_t nb = 0;
+        int64_t nb = 0, nb_f2 = 0;
         for (const GemmProblem& g : s->probs) {
             const int64_t tm = (g.M + GEMM_BIG_BM - 1) / GEMM_BIG_BM, tn = (g.N + GEMM_BIG_BN - 1) / GEMM_BIG_BN;
             const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
-            nb += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+            const int64_t nt = ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+            nb += nt;
+            if (P->dtype == PSGDK_BF16 && gemm_is_fused2_problem<bf16_t>(g)) nb_f2 += nt;
         }
         s->big = nb >= big_min_tiles();
+        // two-output problems with a fused update (Q', R Q, the symmetric Grams): only the 128 x 128 kernel has the register-
+        // resident epilogue for them (in the 256 x 256 one it spills); it wins there although its main loop is slower --
+        // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
+        // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
+        if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
     }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
