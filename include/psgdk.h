@@ -30,13 +30,13 @@ extern "C" {
 #endif
 
 #define PSGDK_VERSION 100
-#define PSGDK_MAX_DIMS 8      /* most dims (after squeeze) of one tensor */
+#define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
 
 /* status codes */
 enum {
     PSGDK_OK = 0,
     PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
-    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (tensors with > 8 dims, LRA rank > 64) */
+    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (LRA rank > 64) */
     PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
     PSGDK_ERR_STATE = 4,       /* call order violated (e.g. arenas not bound) */
     PSGDK_ERR_NLB_TIMEOUT = 5  /* returned ONCE by the first psgdk_update_precond_* call after a cooperative norm-bound launch of an
@@ -61,7 +61,7 @@ int psgdk_last_hip_error(void);
 /* ---- planning: replaces psgd.init_kron's structural half (psgd.py:161-263, dense/diag rule psgd.py:208) -----
  * n_tensors tensors; tensor t has ndim[t] dims (AFTER squeeze(), ..._ddp.py:124) listed consecutively in `dims`.
  * precond_dtype: PSGDK_BF16 | PSGDK_F32 (..._ddp.py:41,58).  use_momentum: allocate the EMA buffers (..._ddp.py:137).
- * Tensors with more than 26 dims -> PSGDK_ERR_INVALID (psgd.py:197-198); with > PSGDK_MAX_DIMS -> PSGDK_ERR_UNSUPPORTED.
+ * Tensors with more than 26 (= PSGDK_MAX_DIMS) dims -> PSGDK_ERR_INVALID (psgd.py:197-198).
  * Tensors with <= 2 dims take the grouped-GEMM path; 3..PSGDK_MAX_DIMS dims a generic mode-product path. */
 int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, const int64_t* dims, double max_size,
                       double max_skew, int precond_dtype, int use_momentum);

@@ -12,6 +12,7 @@ BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
+MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
 class PsgdkError(RuntimeError):

@@ -1563,7 +1563,7 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 2) s.one_per_tile = true;
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
-    if (variant >= 5 && variant <= 10) {      // same tiling, parts of the epilogue's work stripped / the output discarded
+    if (variant >= 5 && variant <= 12) {      // same tiling, parts of the epilogue's work stripped / the output discarded
         alt.probs = s.probs; alt.big = s.big;
         for (auto& q : alt.probs) {
             if (variant == 5 || variant == 6) { q.row_sumsq = nullptr; q.sumsq = nullptr; }
@@ -1572,6 +1572,8 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
             if (variant == 8) q.flags |= GF_DBG_NOEPI;
             if (variant == 9) q.flags |= GF_DBG_TINYOUT;
             if (variant == 10) q.flags |= GF_DBG_PLAINST;
+            if (variant == 11) q.flags |= GF_DBG_DESYNC;
+            if (variant == 12) q.flags |= GF_DBG_DESYNC2;
         }
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }

@@ -261,12 +261,12 @@ class KronEngine:
             g_noise, spd, skh = noise
             gl = [x.to(self.dtype).contiguous() for x in g_noise]
             ga = L.ptr_array(gl)
-            sa = (C.c_void_p * (8 * self.n))()      # PSGDK_MAX_DIMS slots per tensor
-            ka = (C.c_void_p * (8 * self.n))()
+            sa = (C.c_void_p * (L.MAX_DIMS * self.n))()      # PSGDK_MAX_DIMS slots per tensor
+            ka = (C.c_void_p * (L.MAX_DIMS * self.n))()
             for (t, i), x in spd.items():
-                x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * 8 + i] = x.data_ptr()
+                x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * L.MAX_DIMS + i] = x.data_ptr()
             for (t, i), x in skh.items():
-                x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * 8 + i] = x.data_ptr()
+                x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * L.MAX_DIMS + i] = x.data_ptr()
             nz = L.Noise(C.cast(ga, C.POINTER(C.c_void_p)), C.cast(sa, C.POINTER(C.c_void_p)),
                          C.cast(ka, C.POINTER(C.c_void_p)))
             keep += [gl, ga, sa, ka, nz]

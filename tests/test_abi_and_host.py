@@ -74,10 +74,12 @@ def test_plan_factor_kinds_match_init_kron_rule(lib, max_size, max_skew):
 def test_plan_argument_errors(lib):
     from psgd_torch_amd import _lib
     rc, plan = _plan(lib, [(3, 4, 5)])
-    assert rc == 0                                     # 3..8 dims: generic mode-product path
+    assert rc == 0                                     # 3..26 dims: generic mode-product path
     lib.psgdk_plan_destroy(plan)
-    rc, plan = _plan(lib, [tuple([2] * 9)])
-    assert rc == _lib.PSGDK_ERR_UNSUPPORTED            # > PSGDK_MAX_DIMS dims: refused loudly
+    for nd in (9, 26):                                 # up to the reference's own limit (26 einsum letters)
+        rc, plan = _plan(lib, [tuple([2] * nd)], max_size=2 if nd > 12 else float("inf"))
+        assert rc == 0, nd
+        lib.psgdk_plan_destroy(plan)
     rc, plan = _plan(lib, [tuple([2] * 27)])
     assert rc == _lib.PSGDK_ERR_INVALID                # psgd.py:197-198
     rc, plan = _plan(lib, [(4, 0)])

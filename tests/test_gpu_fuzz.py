@@ -47,6 +47,15 @@ def test_long_contracted_dimension_split_k(shape, geom):
     _run_case(900 + len(geom) + shape[0], shape, float("inf"), 4096.0, geom)
 
 
+@pytest.mark.parametrize("shape,geom,max_skew", [((2,) * 9, "Q0.5EQ1.5", 1.0), ((2, 3) * 5, "QEQ", 1.0), ((2,) * 12, "Q0.5EQ1.5", 1.0),
+                                                 ((3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2), "EQ", 1.0),
+                                                 ((2,) * 16, "QUAD", float("inf")), ((2,) * 9, "PRO4P", 1.0)])
+def test_tensors_with_9_to_16_dims(shape, geom, max_skew):
+    """The reference allows up to 26 dims (one einsum letter each, psgd.py:197-198); the mode-product path takes them all.
+    (26 dims of extent 2 would be 2^26 elements with 26 factors: same code, left to the plan-creation test on CPU.)"""
+    _run_case(7000 + len(shape), shape, max_skew, float("inf"), geom)
+
+
 def _run_case(seed, shape, max_skew, max_size, geom):
     import psgd_torch_amd as amd
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)

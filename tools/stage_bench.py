@@ -20,11 +20,11 @@ torch.cuda.synchronize()
 eng = next(iter(opt._buckets.values())).engine
 lib = _lib.lib()
 names = ["upd_a (X P -> Pg^T)", "app_a (ema P -> h)", "gram", "qupd", "rq", "rrq", "P = Q^T Q", "upd_b", "app_b"]
-vnames = {0: "as bound", 1: "lock-step", 2: "1 wg/tile", 3: "128x128", 4: "256x256", 5: "no sums", 6: "no sums/scale", 7: "no stores", 8: "no epilogue", 9: "tiny out", 10: "cached st"}
+vnames = {0: "as bound", 1: "lock-step", 2: "1 wg/tile", 3: "128x128", 4: "256x256", 5: "no sums", 6: "no sums/scale", 7: "no stores", 8: "no epilogue", 9: "tiny out", 10: "cached st", 11: "stagger 1/2", 12: "stagger 1/4"}
 for rnd in range(2):
     for which, nm in list(enumerate(names))[:7]:
         out = []
-        for v in (0, 5, 6, 7, 8):
+        for v in ((0, 5, 6, 7, 8) if len(sys.argv) < 3 else tuple(int(x) for x in sys.argv[2].split(','))):
             ms = C.c_float()
             rc = lib.psgdk_test_stage_bench(eng._plan, which, v, 10, C.byref(ms), _lib.current_stream())
             out.append(f"{vnames[v]} {ms.value * 1e3:7.1f}" if rc == 0 else f"{vnames[v]} rc={rc}")
