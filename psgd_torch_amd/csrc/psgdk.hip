@@ -1182,14 +1182,17 @@ static bool trsm_f32_cores() {
     static const bool v = [] { const char* e = std::getenv("PSGDK_TRSM"); return e && std::string(e) == "f32"; }();
     return v;
 }
-// rows per panel of the bf16 solve: 32 (default: two workgroups per CU) or 64 (PSGDK_TRSM_ROWS=64; A/B runs)
-static int trsm_rows() {
-    static const int v = [] { const char* e = std::getenv("PSGDK_TRSM_ROWS"); return (e && std::atoi(e) == 64) ? 64 : 32; }();
+// shape of the bf16 solve: 0 = 32-row panels, two workgroups per CU; 1 = 64-row panels.  PSGDK_TRSM_SHAPE overrides the default (A/B).
+#define TRSM_SHAPE_DEFAULT 0
+static int trsm_shape() {
+    static const int v = [] { const char* e = std::getenv("PSGDK_TRSM_SHAPE"); const int x = e ? std::atoi(e) : TRSM_SHAPE_DEFAULT;
+                              return (x >= 0 && x <= 1) ? x : TRSM_SHAPE_DEFAULT; }();
     return v;
 }
 static int launch_trsm_bf16(const TrsmJob* jobs, const TrsmTile* tiles, unsigned n_tiles, int max_dp, hipStream_t st, int dbg = 0,
-                            int rows = 0) {
-    if (!rows) rows = trsm_rows();
+                            int shape = -1) {
+    if (shape < 0) shape = trsm_shape();
+    const int rows = shape == 0 ? 32 : 64;
     const unsigned shm = (unsigned)rows * (unsigned)(max_dp + 8) * 2u + 64u * (unsigned)(rows + 4) * 4u;
     static bool attr = false;
     if (!attr) {
@@ -1199,7 +1202,7 @@ static int launch_trsm_bf16(const TrsmJob* jobs, const TrsmTile* tiles, unsigned
     }
     const unsigned n_pan = n_tiles * (64u / (unsigned)rows);
     const unsigned grid = ((n_pan + 7) / 8) * 8;
-    if (rows == 64) hipLaunchKernelGGL(eq_trsm_bf16_kernel<64>, dim3(grid), dim3(256), shm, st, jobs, tiles, (int)n_tiles, dbg);
+    if (shape == 1) hipLaunchKernelGGL(eq_trsm_bf16_kernel<64>, dim3(grid), dim3(256), shm, st, jobs, tiles, (int)n_tiles, dbg);
     else hipLaunchKernelGGL(eq_trsm_bf16_kernel<32>, dim3(grid), dim3(256), shm, st, jobs, tiles, (int)n_tiles, dbg);
     return PSGDK_OK;
 }
@@ -1742,7 +1745,7 @@ int psgdk_test_trsm_bench(const void* Y, const void* U, const void* Ut, void* ou
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int it = -2; it < iters; ++it) {
         if (it == 0) HIPCHK(hipEventRecord(e0, st));
-        if (Ut) { if ((rc = launch_trsm_bf16(tj, tt, (unsigned)tiles.size(), dp, st, dbg & 23, (dbg & 8) ? 64 : 32))) return rc; }
+        if (Ut) { if ((rc = launch_trsm_bf16(tj, tt, (unsigned)tiles.size(), dp, st, dbg & 23, (dbg & 8) ? 1 : 0))) return rc; }
         else hipLaunchKernelGGL(eq_trsm_kernel<bf16_t>, dim3((unsigned)tiles.size()), dim3(256), 0, st, tj, tt);
     }
     HIPCHK(hipEventRecord(e1, st));

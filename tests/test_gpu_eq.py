@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("dt,code,tol,lds_panel", [(torch.float32, 1, 2e-5, False), (torch.bfloat16, 0, 2e-2, False),
-                                                    (torch.bfloat16, 0, 2e-2, True)])
+@pytest.mark.parametrize("dt,code,tol,shape", [(torch.float32, 1, 2e-5, None), (torch.bfloat16, 0, 2e-2, None),
+                                               (torch.bfloat16, 0, 2e-2, 0), (torch.bfloat16, 0, 2e-2, 1)])
 @pytest.mark.parametrize("rows,d", [(1, 40), (100, 64), (70, 200), (300, 768), (1000, 1024), (130, 1088)])
-def test_trsm_right_kernel(dt, code, tol, lds_panel, rows, d):
-    """X = Y inv(U) (psgd.py:288-293) against torch's fp64 solve.  lds_panel: the bf16 kernel the EQ update uses for bf16 state
-    (panel in LDS, bf16 matrix cores for the updates); otherwise the fp32-matrix-core kernel (fp32 state, wide factors)."""
+def test_trsm_right_kernel(dt, code, tol, shape, rows, d):
+    """X = Y inv(U) (psgd.py:288-293) against torch's fp64 solve.  shape None: the fp32-matrix-core kernel (fp32 state, wide
+    factors); 0 / 1: the bf16 kernel with the panel in LDS and the updates on the bf16 matrix cores -- 32-row panels (what the EQ
+    update launches for bf16 state) and 64-row panels."""
+    import ctypes as C
     from psgd_torch_amd import _lib
     lib = _lib.lib()
     g = torch.Generator().manual_seed(rows * 1000 + d)
@@ -30,13 +32,19 @@ def test_trsm_right_kernel(dt, code, tol, lds_panel, rows, d):
     Yp = torch.zeros(rp, dp, dtype=dt); Yp[:rows, :d] = Y.to(dt)
     ref = torch.linalg.solve_triangular(Up[:d, :d].double(), Yp[:rows, :d].double(), upper=True, left=False)
     Ud, Yd = Up.to(DEV), Yp.to(DEV)
-    Utd = Ud.t().contiguous() if lds_panel else None
+    Utd = Ud.t().contiguous() if shape is not None else None
     for use_nat, use_t in [(True, True), (True, False), (False, True)]:
         On = torch.zeros(rp, dp, dtype=dt, device=DEV) if use_nat else None
         Ot = torch.zeros(dp, rp, dtype=dt, device=DEV) if use_t else None
-        _lib.check(lib.psgdk_test_trsm_right(Yd.data_ptr(), Ud.data_ptr(), Utd.data_ptr() if lds_panel else None,
-                                             On.data_ptr() if use_nat else None,
-                                             Ot.data_ptr() if use_t else None, code, rows, d, _lib.current_stream()))
+        if shape in (None, 0):
+            _lib.check(lib.psgdk_test_trsm_right(Yd.data_ptr(), Ud.data_ptr(), Utd.data_ptr() if shape == 0 else None,
+                                                 On.data_ptr() if use_nat else None,
+                                                 Ot.data_ptr() if use_t else None, code, rows, d, _lib.current_stream()))
+        else:          # the other launch shapes are reachable through the timing entry (one launch)
+            ms = C.c_float()
+            _lib.check(lib.psgdk_test_trsm_bench(Yd.data_ptr(), Ud.data_ptr(), Utd.data_ptr(), On.data_ptr() if use_nat else None,
+                                                 Ot.data_ptr() if use_t else None, rows, d, 1, 8, C.byref(ms), None,
+                                                 _lib.current_stream()))
         if use_nat:
             assert relerr(On[:rows, :d], ref) <= tol, (rows, d, "nat", relerr(On[:rows, :d], ref))
             assert float(On[rows:].abs().max() if rows < rp else 0) == 0 and float(On[:, d:].abs().max() if d < dp else 0) == 0
