@@ -31,5 +31,12 @@ rocprofv3 --kernel-trace --stats -d /tmp/p_med -- python $R/bench.py --config gp
 dbm=$(find /tmp/p_med -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $dbm > $out/gpt2-medium_kernel_stats.md
 python $R/tools/rocpd_sequence.py $dbm accumulate_kernel -3 > $out/gpt2-medium_step_sequence.md
+# the EQ geometry and the LRA path under rocprofv3
+rocprofv3 --kernel-trace --stats -d /tmp/p_eq -- python $R/bench.py --config gpt2-small-eq --steps 8 --warmup 2 > /dev/null 2> $out/rocprof_eq.err
+dbe=$(find /tmp/p_eq -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $dbe > $out/gpt2-small-eq_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d /tmp/p_lra -- python $R/bench.py --config vit-b-lra --steps 4 --warmup 1 > /dev/null 2> $out/rocprof_lra.err
+dbl=$(find /tmp/p_lra -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $dbl > $out/vit-b-lra_kernel_stats.md
 python $R/tools/parity_report.py > $out/parity_report.md 2> $out/parity_report.err
 ls -la $out
