@@ -655,12 +655,14 @@ def gen_lra():
     gen_lra_case("n2048_r10", 2048, 10, ("fp64", "fp32", "bf16"), T=3, seed=2)
     gen_lra_case("n257_r1", 257, 1, ("fp64", "fp32"), T=4, lr=0.3, betaL=0.5, damping=1e-3, seed=3)
     gen_lra_case("n300_r0", 300, 0, ("fp64", "fp32", "bf16"), T=3, seed=4)          # rank 0 = diagonal preconditioner
-    gen_lra_case("n1000_r16", 1000, 16, ("fp32", "bf16"), T=3, seed=5)               # the largest rank the HIP kernels hold
-    # beyond it: pins the ORACLE only (prefix keeps it out of the GPU tests' lra_* sweep) -- the fixture for the next rank step
+    gen_lra_case("n1000_r16", 1000, 16, ("fp32", "bf16"), T=3, seed=5)               # the widest rank of the one-thread-per-row class
+    # the wider rank classes of the HIP kernels (two / four threads per row: r <= 32 / <= 64)
     gen_lra_case("n600_r32", 600, 32, ("fp64", "fp32"), T=3, seed=6, prefix="lrabig_")
+    gen_lra_case("n1100_r48", 1100, 48, ("fp32", "bf16"), T=2, seed=7, prefix="lrabig_")
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)
+    gen_lrawhiten_case("momentum_r32", seed=3, rank_of_approximation=32, preconditioner_init_scale=1.0, momentum=0.9)
 
 
 if __name__ == "__main__":

@@ -113,6 +113,57 @@ def test_gpt2_small_shapes_bf16_both_norm_bound_routes(shape, fused, monkeypatch
     assert info["max_dense_dim"] == 768
 
 
+GEOM_FNS = {"EQ": "update_precond_kron_whiten_eq", "QEQ": "update_precond_kron_whiten_qeq", "QUAD": "update_precond_kron_whiten_quad",
+            "QEP": "update_precond_kron_whiten_qep", "QUAD4P": "update_precond_kron_whiten_quad4p"}
+
+
+@pytest.mark.parametrize("shape,geom", [((2304, 768), "EQ"), ((768, 768), "EQ"), ((3072, 768), "EQ"), ((2304, 768), "QEQ"),
+                                        ((768, 768), "QUAD"), ((2304, 768), "QEP"), ((768, 768), "QUAD4P")])
+def test_gpt2_small_shapes_other_geometries_bf16(shape, geom):
+    """The other fitting geometries at GPT-2-small's sizes, bf16, vs the fp64 oracle with replayed noise: for EQ that is the bf16
+    triangular solve with the panel in LDS at d = 768 (both solves for (768,768): row and column factor dense), the K-band
+    skipping of the triangular GEMM operands, and Q' = Q - mu triu(.) Q staying exactly upper triangular (psgd.py:278-336);
+    QEQ / QUAD / QEP / QUAD4P share Pg, the Grams and the norm bound with the default geometry (psgd.py:339-391, 455-513)."""
+    amd = _amd()
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    dt = torch.bfloat16
+    p4 = geom == "QUAD4P"
+    upd_amd, upd_orc = getattr(amd, GEOM_FNS[geom]), getattr(orc, GEOM_FNS[geom])
+    Gs = _structured(shape, 2, 2000 + len(geom))
+    QL, exprs = amd.init_kron(torch.zeros(shape, device=DEV, dtype=dt), Scale=1.0, max_skew=1.0, dQ=geom)
+    QL64, kinds = orc.init_kron(torch.zeros(shape, dtype=torch.float64), Scale=1.0, max_skew=1.0)
+    QLlo, _ = orc.init_kron(torch.zeros(shape, dtype=dt), Scale=1.0, max_skew=1.0)
+    gen = torch.Generator().manual_seed(91)
+    for t in range(2):
+        Gd = Gs[t].to(dt)
+        nz = orc.KronNoise.draw(Gd, kinds, gen)
+        nz.balance_u = 1.0
+        kwargs = dict(lr=0.3, betaL=0.9, damping=1e-9, noise=_dev_noise(nz))
+        if geom != "QEP":
+            kwargs["balance"] = False
+        upd_amd(QL, exprs, Gd.to(DEV), **kwargs)
+        h = amd.precond_grad_kron(QL, exprs, Gd.to(DEV))
+        n64 = orc.KronNoise(nz.g_noise.double(), [x.double() if x is not None else None for x in nz.spd],
+                            [x.double() if x is not None else None for x in nz.skh], 1.0)
+        upd_orc(QL64, Gd.double(), n64, lr=0.3, betaL=0.9, damping=1e-9)
+        upd_orc(QLlo, Gd, orc.KronNoise(nz.g_noise, nz.spd, nz.skh, 1.0), lr=0.3, betaL=0.9, damping=1e-9)
+        ap = orc.precond_grad_kron_4p if p4 else orc.precond_grad_kron
+        checks = [("h", h, ap(QLlo[0], Gd), ap(QL64[0], Gd.double()))]
+        for i in range(len(QL[0])):
+            checks.append((f"Q{i}", QL[0][i], QLlo[0][i], QL64[0][i]))       # no gauge freedom in these geometries: Q itself
+            checks.append((f"L{i}", QL[1][i], QLlo[1][i], QL64[1][i]))
+            if geom == "EQ" and QL[0][i].dim() == 2:
+                assert float(torch.tril(QL[0][i].float(), -1).abs().max()) == 0.0, (shape, i, "Q left the upper triangle")
+        for what, got, low, truth in checks:
+            assert bool(torch.isfinite(torch.as_tensor(got).float()).all()), (shape, geom, t, what, "non-finite")
+            e_hip, e_ref = relerr(got, truth), relerr(low, truth)
+            floor = 2 * ULP if what.startswith("L") else ULP
+            assert e_hip <= 1.5 * e_ref + floor, (shape, geom, t, what, e_hip, e_ref)
+    for i, q in enumerate(QL64[0]):
+        ref = torch.eye(q.shape[0], dtype=torch.float64) if q.dim() == 2 else torch.ones_like(q)
+        assert relerr(q, ref) > 1e-2, (shape, geom, i, "factor did not move")
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_gpt2_small_wte_bf16_splitk_gram(fused, monkeypatch):
     """wte (50304, 768): the mode Gram contracts over K = 50304 (split-K slabs + splitk_reduce_sym), 197 row tiles."""
