@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--whiten-grad", action="store_true", help="variant: fit P on the gradient, apply it to the momentum "
                                                                "(KWNS4(whiten_grad=True)); the headline uses the default False")
     ap.add_argument("--no-roofline", action="store_true", help="do not time the GEMM launches with hipEvents (no roofline "
-                                                               "object): the engine then replays its dense chain as a hipGraph")
+                                                               "object; shows what the event pairs cost the step)")
     ap.add_argument("--no-apply-only", action="store_true", help="skip the secondary apply-only measurement (profiling runs)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
