@@ -289,7 +289,7 @@ def test_kronwhiten_buckets_mixed_dtypes():
 
     def closure():
         return sum(((p.float() - c.float()) ** 2).sum() for p, c in zip(params, tgt))
-    l0 = float(closure())
+    l0 = float(closure().detach())
     for _ in range(30):
         opt.step(closure)
     assert len(opt._engines) == 2 and sorted(i for _, idx in opt._engines for i in idx) == [0, 1, 2]
