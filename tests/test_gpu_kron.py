@@ -294,7 +294,7 @@ def test_kronwhiten_buckets_mixed_dtypes():
         opt.step(closure)
     assert len(opt._engines) == 2 and sorted(i for _, idx in opt._engines for i in idx) == [0, 1, 2]
     assert opt._QLs[1][0][0].dtype == torch.bfloat16 and opt._QLs[0][0][0].dtype == torch.float32
-    assert float(closure()) < 0.5 * l0 and all(bool(torch.isfinite(p).all()) for p in params)
+    assert float(closure().detach()) < 0.5 * l0 and all(bool(torch.isfinite(p).all()) for p in params)
 
 
 @pytest.mark.parametrize("shape,max_skew", [((96, 64), 1.0), ((64, 64), 1.0), ((200,), 1.0), ((48, 80), 0.0),
