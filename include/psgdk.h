@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 100
+#define PSGDK_VERSION 200    /* round 2: PSGDK_MAX_DIMS 8 -> 26 (noise slot arrays), new entry points, PSGDK_ERR_NLB_TIMEOUT */
 #define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
 
 /* status codes */

@@ -12,6 +12,7 @@ BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
+ABI_VERSION = 200      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -124,6 +125,9 @@ def lib():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
+    if L.psgdk_version() != ABI_VERSION:       # a stale libpsgdk.so next to newer Python: its layouts (noise slots per tensor) differ
+        raise PsgdkError(-1, f"{LIB_PATH} has ABI version {L.psgdk_version()}, this package expects {ABI_VERSION}: rebuild it with "
+                             "`python -m psgd_torch_amd.build`")
     _lib = L
     return L
 

@@ -27,7 +27,7 @@ static double nrand(void) { double u1 = urand() + 1e-300, u2 = urand(); return s
 
 int main(void) {
     enum { R = 96, Cc = 64, NW = R * Cc, NB = Cc, STEPS = 60 };
-    if (psgdk_version() < 100) { fprintf(stderr, "unexpected library version\n"); return 1; }
+    if (psgdk_version() != PSGDK_VERSION) { fprintf(stderr, "unexpected library version\n"); return 1; }
     const int32_t ndim[2] = {2, 1};
     const int64_t dims[3] = {R, Cc, Cc};
     psgdk_plan* plan = NULL;
