@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Observed parity of the HIP path against the reference's golden vectors (tests/golden), through the C ABI -- the numbers
-behind the pass/fail thresholds of tests/test_gpu_*.py.  Run on an MI355X:  python tools/parity_report.py > profiles/<name>.md
+behind the pass/fail thresholds of tests/test_gpu_*.py.  Run on an MI355X:  python tests/parity_report.py > profiles/<name>.md  (lives under tests/: it uses the oracle)
 fp32: max over steps of relerr(hip, golden).  bf16: max over steps of relerr(hip, fp64 oracle) next to relerr(reference bf16,
 fp64 oracle) on the same inputs."""
 import os

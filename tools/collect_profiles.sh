@@ -38,5 +38,5 @@ python $R/tools/rocpd_stats.py $dbe > $out/gpt2-small-eq_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/p_lra -- python $R/bench.py --config vit-b-lra --steps 4 --warmup 1 > /dev/null 2> $out/rocprof_lra.err
 dbl=$(find /tmp/p_lra -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $dbl > $out/vit-b-lra_kernel_stats.md
-python $R/tools/parity_report.py > $out/parity_report.md 2> $out/parity_report.err
+python $R/tests/parity_report.py > $out/parity_report.md 2> $out/parity_report.err
 ls -la $out
