@@ -9,8 +9,11 @@ What is different, on purpose:
     device), identical on every rank by construction -- the reference reaches the same lock-step by broadcasting and
     swapping torch RNG states (..._ddp.py:88-104,172-176);
   * `shard_state=True` (new; the reference only replicates): every rank owns a cost-balanced subset of
-    the parameters, preconditions only those, and the clipped preconditioned gradients are exchanged with ONE
-    all-gather (RCCL over xGMI); every rank then applies the identical parameter update.
+    the parameters, preconditions only those, and the clipped preconditioned gradients are exchanged by all-gather
+    (RCCL over xGMI); every rank then applies the identical parameter update.  The tensors are worked off in
+    `shard_chunks` (default 4) cost-balanced chunks, each with its own exchange buffer: chunk c's asynchronous, in-place
+    all-gather travels while chunk c + 1 is preconditioned, and the parameter updates follow chunk by chunk as the
+    gathers land -- on a step this short the fabric, not the arithmetic, is the critical path.
 """
 from __future__ import annotations
 
@@ -60,6 +63,7 @@ class KWNS4(torch.optim.Optimizer):
             *,
             seed: int = 0,
             shard_state: bool = False,
+            shard_chunks: Optional[int] = None,
             engine_factory=None,
     ):
         # the reference's argument checks, verbatim in meaning (..._ddp.py:45-62)
@@ -107,6 +111,10 @@ class KWNS4(torch.optim.Optimizer):
         self.world = torch.distributed.get_world_size() if self.is_distributed else 1
         self.rank = torch.distributed.get_rank() if self.is_distributed else 0
         self.shard_state = bool(shard_state) and self.world > 1
+        # sharded mode: the tensors of a bucket are worked off in this many cost-balanced chunks, each with its own exchange
+        # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (default 4; 1 = one exchange)
+        self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else 4)) if self.shard_state else 1
+        self._chunks = {}            # bucket key -> {position of the parameter in its group: chunk index}
         self._seed = int(seed)
         self._gate_gen = torch.Generator().manual_seed(self._seed)      # same stream on every rank
         self._buckets: Dict[tuple, _Bucket] = {}
@@ -143,12 +151,31 @@ class KWNS4(torch.optim.Optimizer):
 
     # --------------------------------------------------------------------------------------------------------------
     def _buckets_for(self, gi: int, group, plist: List[torch.Tensor]):
-        """[(bucket, params)] covering plist.  Normally one batched bucket.  If the set of parameters with gradients changes
-        between steps (the reference simply skips parameters without a gradient, ..._ddp.py:113-115) the batched bucket is
-        SPLIT once into one single-tensor engine per parameter -- state carried over -- and stays split: correct for any
-        pattern of missing gradients, at the reference's own launch granularity for that group."""
+        """[(bucket, params)] covering plist.  Normally one batched bucket -- in sharded mode `shard_chunks` of them, cut at equal
+        cost, so that the exchange of one chunk overlaps the arithmetic of the next (the chunk of a parameter is fixed when its
+        bucket key is first seen).  If the set of parameters with gradients changes between steps (the reference simply skips
+        parameters without a gradient, ..._ddp.py:113-115) a batched bucket is SPLIT once into one single-tensor engine per
+        parameter -- state carried over -- and stays split: correct for any pattern of missing gradients, at the reference's own
+        launch granularity for that group."""
         p0, g0 = self._data_of(plist[0]), self._grad_of(plist[0])
         key = (gi, p0.dtype, g0.dtype, p0.device)
+        if self._shard_chunks <= 1:
+            return self._buckets_for_key(gi, group, plist, key)
+        pos = {id(p): k for k, p in enumerate(group["params"])}
+        ch = self._chunks.get(key)           # {position in the group: chunk}; part of the checkpoint
+        if ch is None:
+            shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]
+            costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
+            part = lpt_partition(costs, min(self._shard_chunks, len(plist)))      # deterministic: the same on every rank
+            ch = self._chunks[key] = {pos[id(p)]: c for p, c in zip(plist, part)}
+        out = []
+        for c in range(self._shard_chunks):
+            sub = [p for p in plist if ch.get(pos[id(p)], 0) == c]     # (a parameter first seen later joins chunk 0, which then splits)
+            if sub:
+                out += self._buckets_for_key(gi, group, sub, key + ("c", c))
+        return out
+
+    def _buckets_for_key(self, gi: int, group, plist: List[torch.Tensor], key):
         pos = {id(p): k for k, p in enumerate(group["params"])}
         if key in self._split:
             out = []
@@ -159,10 +186,21 @@ class KWNS4(torch.optim.Optimizer):
                 out.append((self._buckets[sk], [p]))
             return out
         b = self._buckets.get(key)
+        if b is None:
+            # resumed from a checkpoint and this bucket has not been rebuilt yet: rebuild it over the parameters it HAD (some of
+            # them may have no gradient on this step), so that its state is restored before the comparison below may split it
+            saved = (getattr(self, "_pending_restore", None) or {}).get(self._key_str(key))
+            if saved is not None and "positions" in saved and saved["positions"] != [pos[id(p)] for p in plist]:
+                had = [group["params"][k] for k in saved["positions"]]
+
+                def _dt(x):
+                    return None if x in (None, "None") else getattr(torch, x.split(".")[-1])
+                b = self._bucket_for(gi, group, had, key=key, shapes=[tuple(self._data_of(p).squeeze().shape) for p in had],
+                                     pd=_dt(saved.get("pd")))
         if b is not None and [id(p) for p in b.params] != [id(p) for p in plist]:
             self._split_bucket(gi, group, key, b, pos)
-            return self._buckets_for(gi, group, plist)
-        return [(self._bucket_for(gi, group, plist), plist)]
+            return self._buckets_for_key(gi, group, plist, key)
+        return [(self._bucket_for(gi, group, plist, key=key), plist)]
 
     def _split_bucket(self, gi, group, key, b, pos):
         self._split.add(key)
@@ -270,12 +308,18 @@ class KWNS4(torch.optim.Optimizer):
             for p in with_grad:
                 lp, lg = self._data_of(p), self._grad_of(p)
                 by_dtype.setdefault((lp.dtype, lg.dtype, lp.device), []).append(p)
+            # two passes over the buckets: first all the arithmetic (sharded: each bucket's exchange is started as soon as its
+            # preconditioned gradients are exported, and travels while the next bucket is worked on), then the parameter updates
+            items = []
             for plist in by_dtype.values():
                 for b, sub in self._buckets_for(gi, group, plist):
-                    self._step_bucket(b, group, sub, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
+                    work = self._bucket_compute(b, group, sub, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
+                    items.append((b, sub, work))
+            for b, sub, work in items:
+                self._bucket_finish(b, group, sub, work)
         self._global_step += 1
 
-    def _step_bucket(self, b, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
+    def _bucket_compute(self, b, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
         wd, lr = group["weight_decay"], group["lr_params"]
         decoupled = group["decoupled_weight_decay"]
         t = b.step
@@ -316,6 +360,11 @@ class KWNS4(torch.optim.Optimizer):
         if eng is not None and updateP_last:
             eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
                                offset=2 * t + 1, **self._update_draws(b, plist))
+        return work
+
+    def _bucket_finish(self, b, group, plist, work):
+        wd, lr = group["weight_decay"], group["lr_params"]
+        decoupled = group["decoupled_weight_decay"]
         if self.shard_state:
             work.wait()
             present = {id(p) for p in plist}
@@ -349,8 +398,10 @@ class KWNS4(torch.optim.Optimizer):
     def state_dict(self):
         buckets = {}
         for key, b in self._buckets.items():
+            gpos = {id(p): k for k, p in enumerate(self.param_groups[key[0]]["params"])}
             buckets[self._key_str(key)] = {
                 "group": key[0], "n_params": len(b.params), "owned": list(b.owned), "step": b.step,
+                "positions": [gpos[id(p)] for p in b.params], "pd": str(b.pd),
                 "arena": b.engine.state_arena.detach().clone().cpu() if b.engine is not None else None,
             }
         # param_groups as torch.optim.Optimizer.state_dict() lays them out: hyper-parameters + 'params' as running indices
@@ -360,10 +411,13 @@ class KWNS4(torch.optim.Optimizer):
             d["params"] = list(range(start, start + len(g["params"])))
             start += len(g["params"])
             groups.append(d)
-        split = [{"key": self._key_str(k), "parts": [k[0], str(k[1]), str(k[2]), str(k[3])], "pd": str(self._split_pd.get(k))}
-                 for k in self._split]
+        def parts(k):      # (group, param dtype, grad dtype, device[, "c", chunk][, "p", position]) in a form that survives pickling
+            return [k[0], str(k[1]), str(k[2]), str(k[3])] + list(k[4:])
+        split = [{"key": self._key_str(k), "parts": parts(k), "pd": str(self._split_pd.get(k))} for k in self._split]
+        split_owner = [{"parts": parts(k), "owner": list(v)} for k, v in self._split_owner.items()]
         return {"psgdk_version": 2, "state": {},      # per-parameter state lives in the bucket arenas below
-                "param_groups": groups, "split": split,
+                "param_groups": groups, "split": split, "split_owner": split_owner, "shard_chunks": self._shard_chunks,
+                "chunks": [{"parts": parts(k), "of": dict(v)} for k, v in self._chunks.items()],
                 "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
 
     def load_state_dict(self, sd):
@@ -381,9 +435,17 @@ class KWNS4(torch.optim.Optimizer):
 
         def _dt(s):
             return None if s == "None" else getattr(torch, s.split(".")[-1])
+        assert sd.get("shard_chunks", 1) == self._shard_chunks, "checkpoint was taken with another shard_chunks"
+
+        def _key(parts):
+            gi, pdt, gdt, dev = parts[:4]
+            return (int(gi), _dt(pdt), _dt(gdt), torch.device(dev)) + tuple(parts[4:])
+        for e in sd.get("split_owner", []):
+            self._split_owner[_key(e["parts"])] = list(e["owner"])
+        for e in sd.get("chunks", []):
+            self._chunks[_key(e["parts"])] = {int(k): int(v) for k, v in e["of"].items()}
         for e in sd.get("split", []):
-            gi, pdt, gdt, dev = e["parts"]
-            key = (int(gi), _dt(pdt), _dt(gdt), torch.device(dev))
+            key = _key(e["parts"])
             if key not in self._split:
                 if key in self._buckets:      # a batched bucket already exists here: drop it, its state comes from the checkpoint
                     del self._buckets[key]

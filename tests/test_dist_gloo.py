@@ -23,13 +23,22 @@ def _make(seed):
 MISSING = [set(), {2}, set(), {0, 4}, {0, 4, 7}, set()]      # parameters WITHOUT a gradient, per step (the `missing` cases)
 
 
-def _run(params, steps, shard, missing=False, **kw):
+def _run(params, steps, shard, missing=False, resume=False, **kw):
     import psgd_torch_amd
     from oracle_engine import OracleEngine
-    opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=shard,
-                               lr_params=1e-2, **kw)
+    if not shard:
+        kw.pop("shard_chunks", None)
+
+    def make():
+        return psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=shard,
+                                    lr_params=1e-2, **kw)
+    opt = make()
     g = torch.Generator().manual_seed(99)
     for t in range(steps):
+        if resume and shard and t == 3:       # checkpoint / resume in the middle of the sharded run (after a bucket split, if any)
+            sd = opt.state_dict()
+            opt = make()
+            opt.load_state_dict(sd)
         for i, p in enumerate(params):
             gr = 0.3 * torch.randn(p.shape, generator=g)
             p.grad = None if (missing and i in MISSING[t % len(MISSING)]) else gr
@@ -46,7 +55,8 @@ def _worker(rank, world, port, outdir, kw):
         params = _make(7)
         opt = _run(params, 6 if kw.get("missing") else 4, True, **kw)
         owned = [len(b.owned) for b in opt._buckets.values()]
-        torch.save({"params": [p.data.clone() for p in params], "owned": owned}, os.path.join(outdir, f"r{rank}.pt"))
+        torch.save({"params": [p.data.clone() for p in params], "owned": owned, "n_buckets": len(opt._buckets)},
+                   os.path.join(outdir, f"r{rank}.pt"))
     finally:
         torch.distributed.destroy_process_group()
 
@@ -61,7 +71,9 @@ def _free_port():
 
 @pytest.mark.parametrize("kw", [dict(), dict(whiten_grad=True, update_preconditioner_first=False, weight_decay=0.0),
                                 dict(preconditioner_update_probability=0.5, momentum=0.5),
-                                dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02)])
+                                dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02),
+                                dict(shard_chunks=1), dict(shard_chunks=3, update_preconditioner_first=False),
+                                dict(missing=True, shard_chunks=2), dict(resume=True), dict(missing=True, resume=True)])
 def test_sharded_equals_replicated(kw):
     """(missing=True: some parameters have no gradient on some steps -- the reference skips them, ..._ddp.py:113-115; the
     sharded optimizer splits its bucket per parameter, every parameter keeping its owner, and skips their update and decay.)"""
@@ -70,13 +82,15 @@ def test_sharded_equals_replicated(kw):
     if here not in sys.path:
         sys.path.insert(0, here)
     ref_params = _make(7)
-    _run(ref_params, 6 if kw.get("missing") else 4, False, **kw)
+    _run(ref_params, 6 if kw.get("missing") else 4, False, **{k: v for k, v in kw.items() if k != "resume"})
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, _free_port(), d, kw), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "r0.pt"))
         r1 = torch.load(os.path.join(d, "r1.pt"))
     if not kw.get("missing"):
         assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
+        # (default: 4 chunks per bucket, each with its own exchange; shard_chunks=1: one)
+        assert r0["n_buckets"] == min(kw.get("shard_chunks", 4), len(SHAPES)), r0["n_buckets"]
     for a, b, c in zip(r0["params"], r1["params"], ref_params):
         assert torch.equal(a, b), "ranks diverged"
         assert torch.allclose(a, c.data, rtol=0, atol=0), "sharded result differs from the single-process result"

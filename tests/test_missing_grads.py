@@ -91,3 +91,36 @@ def test_checkpoint_round_trip_after_a_bucket_split():
         assert oa.state[a]["step"] == ob.state[b]["step"]
         for qa, qb in zip(oa.state[a]["QL"][0], ob.state[b]["QL"][0]):
             assert torch.equal(qa, qb)
+
+
+def test_resume_right_before_the_first_missing_gradient():
+    """Checkpoint taken while the bucket is still batched, resumed at a step on which a parameter has no gradient: the batched
+    bucket is rebuilt over the parameters it HAD (from the checkpoint), its state restored, and only then split -- bit for bit the
+    uninterrupted run."""
+    import copy
+    import psgd_torch_amd
+    kw = dict(preconditioner_dtype=torch.float32, lr_params=1e-2, lr_preconditioner=0.3, momentum=0.9, weight_decay=0.01)
+    gg = torch.Generator().manual_seed(99)
+    stream = [[0.3 * torch.randn(s, generator=gg) for s in SHAPES] for _ in range(6)]
+    pattern = [set(), set(), {0, 3}, {3}, set(), {1}]
+
+    def run(opt, params, lo, hi):
+        for t in range(lo, hi):
+            for i, p in enumerate(params):
+                p.grad = None if i in pattern[t] else stream[t][i].clone()
+            opt.step()
+    pa = _params(4)
+    oa = psgd_torch_amd.KWNS4(pa, engine_factory=OracleEngine, seed=5, **kw)
+    run(oa, pa, 0, 2)
+    assert not oa._split
+    sd = copy.deepcopy(oa.state_dict())
+    snap = [p.detach().clone() for p in pa]
+    run(oa, pa, 2, 6)
+    assert oa._split
+    pb = [torch.nn.Parameter(x.clone()) for x in snap]
+    ob = psgd_torch_amd.KWNS4(pb, engine_factory=OracleEngine, seed=77, **kw)
+    ob.load_state_dict(sd)
+    run(ob, pb, 2, 6)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a.data, b.data), f"parameter {i} differs after resume"
+        assert oa.state[a]["step"] == ob.state[b]["step"]
