@@ -46,7 +46,10 @@ struct psgdk_plan {
     GenDesc* d_gd = nullptr;
     std::vector<int> gram_prob;                      // per dense factor: its problem in g_gram, or -1 (N-D tensors)
     size_t state_bytes = 0, work_bytes = 0;
-    size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0, diag_mu_off = 0;
+    size_t zero_off = 0, zero_bytes = 0, hsumsq_off = 0, balnorm_off = 0, diag_mu_off = 0;
+    // the balancing norms live inside the zero region: an update's one memset leaves them clean for the balancing step at its end
+    // (the sums of h^2 stay outside: an update may run between precond_grad and the consumers of h)
+    bool bal_clean = false;
     int max_diag_len = 0;
     unsigned char* state = nullptr;
     unsigned char* work = nullptr;
@@ -62,7 +65,7 @@ struct psgdk_plan {
                                                             // when a call passes the same addresses as the previous one)
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
-    int* d_balance = nullptr; float* d_balnorm = nullptr;
+    int* d_balance = nullptr;
     int max_dp = 0;
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
@@ -102,7 +105,7 @@ struct psgdk_plan {
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
-        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_balnorm); fr(d_gd);
+        fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
@@ -251,6 +254,7 @@ static void layout_arenas(psgdk_plan* P) {
     for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
     if (P->geometry == PSGDK_GEOM_EQ)
         for (auto& G : P->dd) { G.sum2_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
+    P->balnorm_off = wo; wo += align256((size_t)n_tensors * 2 * 4);
     P->zero_bytes = wo - P->zero_off;
     P->hsumsq_off = wo; wo += align256((size_t)n_tensors * 4);
     P->diag_mu_off = wo; wo += align256((P->dd.size() + 1) * 4);
@@ -537,8 +541,6 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if ((rc = alloc_ptrs(&P->d_noise_skh, P->dn.size()))) return rc;
     if (P->d_balance) { (void)hipFree(P->d_balance); P->d_balance = nullptr; }
     HIPCHK(hipMalloc((void**)&P->d_balance, P->n_tensors * sizeof(int)));
-    if (P->d_balnorm) { (void)hipFree(P->d_balnorm); P->d_balnorm = nullptr; }
-    HIPCHK(hipMalloc((void**)&P->d_balnorm, 2 * P->n_tensors * sizeof(float)));
     if (P->d_scale_diag) { (void)hipFree(P->d_scale_diag); P->d_scale_diag = nullptr; }
     if (P->d_scale_dense) { (void)hipFree(P->d_scale_dense); P->d_scale_dense = nullptr; }
     HIPCHK(hipMalloc((void**)&P->d_scale_diag, std::max<size_t>(P->dd.size(), 1) * 4));
@@ -840,11 +842,13 @@ static int run_balance(psgdk_plan* P, const uint8_t* balance_mask, hipStream_t s
                 DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
         if (!which.empty()) {
             HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemsetAsync(P->d_balnorm, 0, 2 * which.size() * sizeof(float), st));
+            float* balnorm = (float*)(P->work + P->balnorm_off);
+            if (!P->bal_clean) HIPCHK(hipMemsetAsync(balnorm, 0, 2 * which.size() * sizeof(float), st));
+            P->bal_clean = false;
             const dim3 bg(64, (unsigned)(2 * which.size()));
             for (int phase = 0; phase < 2; ++phase)
                 DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, bg, dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
-                                                 P->d_balance, P->state, P->d_balnorm, phase));
+                                                 P->d_balance, P->state, balnorm, phase));
         }
     }
     return PSGDK_OK;
@@ -1030,6 +1034,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
     HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    P->bal_clean = true;
     if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
         std::vector<uint8_t> all(P->n_tensors, 1);
         if ((rc = run_balance(P, all.data(), st))) return rc;
@@ -1233,6 +1238,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     const void* const* ng = noise ? (const void* const*)P->d_noise_g : nullptr;
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
     HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    P->bal_clean = true;
     P->x_valid = false;
     // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336)
     DISPATCH_T(P, hipLaunchKernelGGL(eq_make_xv_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
