@@ -114,11 +114,12 @@ def test_gpt2_small_shapes_bf16_both_norm_bound_routes(shape, fused, monkeypatch
 
 
 GEOM_FNS = {"EQ": "update_precond_kron_whiten_eq", "QEQ": "update_precond_kron_whiten_qeq", "QUAD": "update_precond_kron_whiten_quad",
-            "QEP": "update_precond_kron_whiten_qep", "QUAD4P": "update_precond_kron_whiten_quad4p"}
+            "QEP": "update_precond_kron_whiten_qep", "QUAD4P": "update_precond_kron_whiten_quad4p",
+            "PRO4P": "update_precond_kron_whiten_pro4p"}
 
 
 @pytest.mark.parametrize("shape,geom", [((2304, 768), "EQ"), ((768, 768), "EQ"), ((3072, 768), "EQ"), ((2304, 768), "QEQ"),
-                                        ((768, 768), "QUAD"), ((2304, 768), "QEP"), ((768, 768), "QUAD4P")])
+                                        ((768, 768), "QUAD"), ((2304, 768), "QEP"), ((768, 768), "QUAD4P"), ((1536, 768), "PRO4P")])
 def test_gpt2_small_shapes_other_geometries_bf16(shape, geom):
     """The other fitting geometries at GPT-2-small's sizes, bf16, vs the fp64 oracle with replayed noise: for EQ that is the bf16
     triangular solve with the panel in LDS at d = 768 (both solves for (768,768): row and column factor dense), the K-band
@@ -126,8 +127,8 @@ def test_gpt2_small_shapes_other_geometries_bf16(shape, geom):
     QEQ / QUAD / QEP / QUAD4P share Pg, the Grams and the norm bound with the default geometry (psgd.py:339-391, 455-513)."""
     amd = _amd()
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
-    dt = torch.bfloat16
-    p4 = geom == "QUAD4P"
+    dt = torch.float32 if geom == "PRO4P" else torch.bfloat16     # (PRO4P's data-dependent number of rotations: fp32, as in the fuzz test)
+    p4 = geom in ("QUAD4P", "PRO4P")
     upd_amd, upd_orc = getattr(amd, GEOM_FNS[geom]), getattr(orc, GEOM_FNS[geom])
     Gs = _structured(shape, 2, 2000 + len(geom))
     QL, exprs = amd.init_kron(torch.zeros(shape, device=DEV, dtype=dt), Scale=1.0, max_skew=1.0, dQ=geom)
@@ -138,15 +139,25 @@ def test_gpt2_small_shapes_other_geometries_bf16(shape, geom):
         Gd = Gs[t].to(dt)
         nz = orc.KronNoise.draw(Gd, kinds, gen)
         nz.balance_u = 1.0
-        kwargs = dict(lr=0.3, betaL=0.9, damping=1e-9, noise=_dev_noise(nz))
+        dn = _dev_noise(nz)
+        pro = pro64 = None
+        if geom == "PRO4P":       # ten draws per dense factor for the successive procrustes_step3 calls (psgd.py:422-452), stacked for the ABI
+            pro = [None if x is None else [torch.randn(x.shape, generator=gen).to(dt) for _ in range(10)] for x in nz.skh]
+            pro64 = [None if p_ is None else [y.double() for y in p_] for p_ in pro]
+            dn = (dn[0], dn[1], {(0, i): torch.cat(p_, dim=0).to(DEV) for i, p_ in enumerate(pro) if p_ is not None})
+        kwargs = dict(lr=0.3, betaL=0.9, damping=1e-9, noise=dn)
         if geom != "QEP":
             kwargs["balance"] = False
         upd_amd(QL, exprs, Gd.to(DEV), **kwargs)
         h = amd.precond_grad_kron(QL, exprs, Gd.to(DEV))
         n64 = orc.KronNoise(nz.g_noise.double(), [x.double() if x is not None else None for x in nz.spd],
                             [x.double() if x is not None else None for x in nz.skh], 1.0)
-        upd_orc(QL64, Gd.double(), n64, lr=0.3, betaL=0.9, damping=1e-9)
-        upd_orc(QLlo, Gd, orc.KronNoise(nz.g_noise, nz.spd, nz.skh, 1.0), lr=0.3, betaL=0.9, damping=1e-9)
+        if geom == "PRO4P":
+            upd_orc(QL64, Gd.double(), n64, pro64, lr=0.3, betaL=0.9, damping=1e-9)
+            upd_orc(QLlo, Gd, orc.KronNoise(nz.g_noise, nz.spd, nz.skh, 1.0), pro, lr=0.3, betaL=0.9, damping=1e-9)
+        else:
+            upd_orc(QL64, Gd.double(), n64, lr=0.3, betaL=0.9, damping=1e-9)
+            upd_orc(QLlo, Gd, orc.KronNoise(nz.g_noise, nz.spd, nz.skh, 1.0), lr=0.3, betaL=0.9, damping=1e-9)
         ap = orc.precond_grad_kron_4p if p4 else orc.precond_grad_kron
         checks = [("h", h, ap(QLlo[0], Gd), ap(QL64[0], Gd.double()))]
         for i in range(len(QL[0])):
@@ -158,7 +169,10 @@ def test_gpt2_small_shapes_other_geometries_bf16(shape, geom):
             assert bool(torch.isfinite(torch.as_tensor(got).float()).all()), (shape, geom, t, what, "non-finite")
             e_hip, e_ref = relerr(got, truth), relerr(low, truth)
             floor = 2 * ULP if what.startswith("L") else ULP
-            assert e_hip <= 1.5 * e_ref + floor, (shape, geom, t, what, e_hip, e_ref)
+            if dt == torch.float32:          # (rotations of a fitted P amplify fp32 rounding: psgd.py:425-426; same bound as the fuzz test)
+                assert e_hip <= 2e-3, (shape, geom, t, what, e_hip, e_ref)
+            else:
+                assert e_hip <= 1.5 * e_ref + floor, (shape, geom, t, what, e_hip, e_ref)
     for i, q in enumerate(QL64[0]):
         ref = torch.eye(q.shape[0], dtype=torch.float64) if q.dim() == 2 else torch.ones_like(q)
         assert relerr(q, ref) > 1e-2, (shape, geom, i, "factor did not move")
