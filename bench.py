@@ -167,7 +167,8 @@ def bench_eq(args):
     eng = KronEngine(shapes, dev, precond_dtype=torch.bfloat16, max_skew=1.0, use_momentum=True, init_scale=1.0, geometry="EQ")
 
     def one_step(i):
-        eng.accumulate(grads[i % 2], beta=0.9, keep_grad=False)
+        # (the momentum pass also writes the update's probe V and damped input, as KWNS4 / KronWhiten ask it to)
+        eng.accumulate(grads[i % 2], beta=0.9, keep_grad=False, damp=dict(source=L.SRC_EMA, damping=1e-9, seed=1, offset=i))
         eng.update_precond(L.SRC_EMA, 0.1, 0.9, 1e-9, seed=1, offset=i, balance_mask=None)
         eng.precond_grad(L.SRC_EMA)
         eng.apply_update(params, 2e-4, 0.0, 2.0, 10.0)

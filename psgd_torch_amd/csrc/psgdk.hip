@@ -559,6 +559,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // P = Q^T Q = Qt Qt^T
         g.A = S + F.qt_off; g.B = S + F.qt_off; g.C = W + F.p_off; g.Ct = g.C;
         g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.flags = GF_SYM;
+        // triangular geometry: Q stays exactly upper triangular (psgd.py:316 applies triu), so Qt[m][k] = 0 for k > m
+        if (P->geometry == PSGDK_GEOM_EQ) g.flags |= GF_KBAND_A_LO | GF_KBAND_B_LO;
         P->g_P.probs.push_back(g);
         // mode Gram term1 (psgd.py:405): col factor: Pgt Pgt^T; row factor: Pg Pg^T  (N-D tensors: kernels_gen.hiph)
         P->gram_prob.push_back(D.kind == TK_GEN ? -1 : (int)P->g_gram.probs.size());
@@ -893,7 +895,7 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
                                         plan->d_tiles_all, (const void* const*)plan->d_ptr_a, (const void* const*)plan->d_ptr_b,
                                         plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
-                                        do_x, x_from_grad, damping, ng, seed, offset));
+                                        do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0));
     HIPCHK(hipGetLastError());
     if (damp) {
         plan->x_valid = true; plan->x_source = damp->source; plan->x_damping = damp->damping;
@@ -1239,10 +1241,13 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
     HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
     P->bal_clean = true;
+    // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336), unless psgdk_accumulate already wrote exactly this pair
+    const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
+                         P->x_offset == offset && P->x_explicit == (noise != nullptr);
     P->x_valid = false;
-    // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336)
-    DISPATCH_T(P, hipLaunchKernelGGL(eq_make_xv_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
-                                     P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
+    if (!x_ready)
+        DISPATCH_T(P, hipLaunchKernelGGL(eq_make_xv_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
+                                         P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
     // A = (kron Q) Hvp (psgd.py:295) and B = V x_i Q_i^{-T} (psgd.py:297-303)
     launch_stage(P, P->e_a1, st);
     launch_stage(P, P->e_a2, st);
