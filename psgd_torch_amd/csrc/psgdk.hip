@@ -777,9 +777,10 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least three full rounds of its tiles (one
     // workgroup per CU; 560 tiles = 2.19 rounds cost three, and the 128 x 128 kernel's finer tiles then fill the chip
     // better: -2.4 % of the GPT-2-small step with the threshold at 768 instead of 512).  The subspace iteration
-    // (M = 64) and the EQ stages stay on the small tiling.  Both tilings accumulate K in the same order: same bits.
+    // (M = 64) and the EQ Grams / update stay on the small tiling; EQ's A = (kron Q) Hvp is a full-size product like upd_a.
+    // Both tilings accumulate K in the same order: same bits.
     for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1],
-                     &P->g_app_b}) {
+                     &P->g_app_b, &P->e_a1, &P->e_a2}) {
         int64_t nb = 0, nb_f2 = 0;
         for (const GemmProblem& g : s->probs) {
             const int64_t tm = (g.M + GEMM_BIG_BM - 1) / GEMM_BIG_BM, tn = (g.N + GEMM_BIG_BN - 1) / GEMM_BIG_BN;
