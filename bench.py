@@ -6,7 +6,7 @@ of wrapped_as_torch_optimizer_for_ddp.py:98-176 -- momentum EMA, preconditioner 
 Q0.5EQ1.5 geometry, preconditioning, clipping, parameter update -- with bf16 preconditioner state, fp32 parameters and
 synthetic fp32 gradients already resident in HBM.  N > 1: either preconditioner state sharded per parameter across the
 ranks (shard_state=True; the clipped preconditioned gradients are exchanged with one all-gather) or plain replicas --
---parallelism auto (default) times both in warm-up and keeps the faster; total work is fixed, so scaling is "strong".
+--parallelism auto (default) times the sharded mode (chunked and single-exchange) and plain replicas in warm-up and keeps the fastest; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline     -- for the dominant kernel (the grouped NT MFMA GEMM, both tilings): the algorithmic FLOPs of a step that run in
@@ -286,10 +286,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    def make(shard):
+    MODES = {"sharded": dict(shard_state=True),                         # 4 chunks: each chunk's all-gather under the next one's arithmetic
+             "sharded, one exchange": dict(shard_state=True, shard_chunks=1),
+             "replicated": dict(shard_state=False), "single": dict(shard_state=False)}
+
+    def make(mode_name):
         ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
-        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, shard_state=shard,
-                                        whiten_grad=args.whiten_grad)                     # reference defaults otherwise
+        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, whiten_grad=args.whiten_grad,
+                                        **MODES[mode_name])                                # reference defaults otherwise
 
     def step_of(ps, o):
         def f(i):
@@ -307,8 +311,8 @@ def main():
         mode = "replicated"
     if dist and args.parallelism == "auto":
         timing = {}
-        for name, shard in (("sharded", True), ("replicated", False)):
-            ps_, o_ = make(shard)
+        for name in ("sharded", "sharded, one exchange", "replicated"):
+            ps_, o_ = make(name)
             f_ = step_of(ps_, o_)
             for i in range(3):
                 f_(i)
@@ -323,7 +327,7 @@ def main():
             del ps_, o_, f_
             torch.cuda.empty_cache()
         mode = min(timing, key=timing.get)
-    params, opt = make(mode == "sharded")
+    params, opt = make(mode)
     one_step = step_of(params, opt)
 
     for i in range(args.warmup):
@@ -418,8 +422,9 @@ def main():
                                + ("; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)" if not args.whiten_grad
                                   else "; KWNS4 defaults except whiten_grad=True (momentum 0.9, update probability 1, max_skew 1)"),
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
-                   "parallelism": "single GPU" if world == 1 else (f"per-parameter state sharding x{world} + one all-gather per step"
-                                                                   if mode == "sharded" else f"replicas x{world} (no exchange step)"),
+                   "parallelism": "single GPU" if world == 1 else ({"sharded": f"per-parameter state sharding x{world}, all-gathers of 4 chunks overlapped with the arithmetic",
+                                                                    "sharded, one exchange": f"per-parameter state sharding x{world} + one all-gather per step"}.get(
+                                                                       mode, f"replicas x{world} (no exchange step)")),
                    "parallelism_probe_ms": ({k: v * 1e3 for k, v in timing.items()} if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                    "apply_only_ms_per_step": apply_only_ms,

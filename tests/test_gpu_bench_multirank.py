@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+@pytest.mark.parametrize("mode", ["sharded", "replicated", "auto"])
 def test_bench_two_ranks_one_device(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
@@ -34,4 +34,8 @@ def test_bench_two_ranks_one_device(mode):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert out["config"]["state_finite_after_timed_region"] is True
-    assert ("sharding" in out["config"]["parallelism"]) == (mode == "sharded")
+    if mode == "auto":       # the warm-up probe timed all three modes and the line says which one ran
+        assert sorted(out["config"]["parallelism_probe_ms"]) == ["replicated", "sharded", "sharded, one exchange"], out["config"]
+        assert all(v > 0 for v in out["config"]["parallelism_probe_ms"].values())
+    else:
+        assert ("sharding" in out["config"]["parallelism"]) == (mode == "sharded")
