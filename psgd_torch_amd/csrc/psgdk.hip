@@ -1861,7 +1861,18 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
                 HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
             hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
         }
-        hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+        if constexpr (TPR == 1)
+            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+        else {      // wider rank classes: the rotation on the fp32 matrix cores (PSGDK_LRA_ROTATE=valu keeps the one-row-per-thread form: A/B)
+            static const bool valu = [] { const char* e = std::getenv("PSGDK_LRA_ROTATE"); return e && e[0] == 'v'; }();
+            if (valu)
+                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+            else {
+                const int rows_m = LRA_ROWS / TPR;
+                const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
+                hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+            }
+        }
         hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
         hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
                            (const T*)h, Qh, iq, N, r, sm);
