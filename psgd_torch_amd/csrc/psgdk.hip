@@ -1827,7 +1827,7 @@ int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void*
 // static LDS), and as many workgroups as are resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
 static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm) {
     const int rows = LRA_ROWS / lra_tpr_of_rank(r);
-    const unsigned bytes = (unsigned)std::max(16, mats * rows * r * 4);
+    const unsigned bytes = (unsigned)std::max(16, mats * rows * lra_lds_stride(r) * 4);      // (padded row stride for r > 16)
     const unsigned per_cu = std::max(1u, std::min(8u, (160u * 1024u) / (bytes + fixed + 1024u)));
     const int64_t blocks = (N + rows - 1) / rows;
     *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * (int64_t)per_cu));
