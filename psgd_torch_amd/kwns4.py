@@ -24,7 +24,7 @@ import torch
 
 from . import _lib as L
 from .engine import KronEngine
-from .sharding import lpt_partition, kron_step_cost
+from .sharding import chunk_partition, lpt_partition, kron_step_cost
 
 
 class _Bucket:
@@ -166,7 +166,7 @@ class KWNS4(torch.optim.Optimizer):
         if ch is None:
             shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]
             costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
-            part = lpt_partition(costs, min(self._shard_chunks, len(plist)))      # deterministic: the same on every rank
+            part = chunk_partition(costs, self._shard_chunks, self.world)         # deterministic: the same on every rank
             ch = self._chunks[key] = {pos[id(p)]: c for p, c in zip(plist, part)}
         out = []
         for c in range(self._shard_chunks):

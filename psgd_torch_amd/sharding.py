@@ -35,3 +35,21 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[int]:
         owner[i] = r
         load[r] += costs[i]
     return owner
+
+
+def chunk_partition(costs: Sequence[float], n_chunks: int, world: int) -> List[int]:
+    """Chunk index of every tensor for the sharded step (kwns4.py): LPT over `n_chunks` chunks of equal cost, then the chunks
+    numbered by the time their slowest rank needs (LPT over the ranks inside each chunk), ascending.  A chunk's all-gather can
+    only start when its slowest rank has exported, and the gathers run in launch order: the chunk that holds one dominant
+    tensor (GPT-2's wte: most of its chunk's cost on one rank) goes LAST, so that the other chunks' gathers are on the wire while
+    that rank works through it.  Deterministic on every rank."""
+    n_chunks = max(1, min(n_chunks, len(costs)))
+    part = lpt_partition(costs, n_chunks)
+    crit = []
+    for c in range(n_chunks):
+        cc = [x for x, k in zip(costs, part) if k == c]
+        owner = lpt_partition(cc, world)
+        crit.append(max([sum(x for x, o in zip(cc, owner) if o == r) for r in range(world)] + [0.0]))
+    order = sorted(range(n_chunks), key=lambda c: (crit[c], c))
+    rank_of = {c: k for k, c in enumerate(order)}
+    return [rank_of[k] for k in part]

@@ -207,6 +207,30 @@ def test_lpt_partition_properties():
         assert [("dense" if d else "diag") for d in kron_factor_kinds(s, float("inf"), 1.0)] == orc.kron_factor_kinds(s)
 
 
+def test_sharded_chunks_are_balanced_and_ordered():
+    """The sharded step works the tensors off in cost-balanced chunks (sharding.chunk_partition: LPT over the chunks, LPT over the
+    ranks inside a chunk, chunks numbered by their slowest rank's load): on GPT-2-small / -medium at world 8 with 4 chunks the
+    chunks carry equal cost, all but the one that holds wte are level across the ranks, and that one comes LAST (its gather
+    cannot start before the wte owner has finished; the other chunks' gathers travel meanwhile)."""
+    from psgd_torch_amd.sharding import chunk_partition, kron_step_cost, lpt_partition
+    import bench
+    for shapes in (bench.gpt2_shapes(), bench.gpt2_shapes(n_layer=24, n_embd=1024)):
+        costs = [kron_step_cost(s) for s in shapes]
+        chunk = chunk_partition(costs, 4, 8)
+        assert chunk == chunk_partition(costs, 4, 8) and set(chunk) == {0, 1, 2, 3}
+        per_chunk = [sum(c for c, k in zip(costs, chunk) if k == j) for j in range(4)]
+        assert max(per_chunk) / (sum(per_chunk) / 4) <= 1.05, per_chunk
+        crit = []
+        for j in range(4):
+            cc = [c for c, k in zip(costs, chunk) if k == j]
+            owner = lpt_partition(cc, 8)
+            loads = [sum(c for c, o in zip(cc, owner) if o == r) for r in range(8)]
+            assert set(owner) == set(range(8)), "every rank owns something in every chunk"
+            crit.append(max(loads) / (sum(loads) / 8))
+        assert crit == sorted(crit) and all(x <= 1.15 for x in crit[:3]), crit
+        assert chunk[0] == 3, "wte (the first tensor) sits in the last chunk"
+
+
 def test_flop_model_matches_survey():
     import bench
     step, gemm = bench.flop_model(bench.gpt2_shapes())
