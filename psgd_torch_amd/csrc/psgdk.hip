@@ -1,7 +1,7 @@
 // psgdk.hip -- C-ABI implementation (see include/psgdk.h).  One translation unit; kernels live in the .hiph files.
 //
 // A plan lays every tensor of an optimizer (or one tensor, for the functional seam) out in two caller-owned arenas
-// and pre-builds, once, the grouped-GEMM problem/tile tables of every stage.  A step is then ~30 grouped launches
+// and pre-builds, once, the grouped-GEMM problem/tile tables of every stage.  A step is then ~26 grouped launches
 // over ALL tensors (the reference issues ~100 ATen launches per tensor), with every scalar kept on the device.
 #include "host_util.hiph"
 #include "descs.hiph"
