@@ -351,7 +351,7 @@ def test_kronwhiten_closure_shell():
 
     def loss_of(ps):
         return sum((((p - t) * s) ** 2).sum() for p, t, s in zip(ps, targets, scales))
-    l0 = float(loss_of(p_a))
+    l0 = float(loss_of(p_a).detach())
     for it in range(60):
         opt_a.step(lambda: loss_of(p_a))
         opt_b.zero_grad()
@@ -359,14 +359,14 @@ def test_kronwhiten_closure_shell():
         opt_b.step()
     for a, b in zip(p_a, p_b):
         assert relerr(a.data, b.data) < 1e-4, relerr(a.data, b.data)
-    assert float(loss_of(p_a)) < 0.05 * l0, (l0, float(loss_of(p_a)))
+    assert float(loss_of(p_a).detach()) < 0.05 * l0, (l0, float(loss_of(p_a).detach()))
     # on-the-fly initial scale (psgd.py:599-602) + gradient whitening without momentum
     p_c = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
     opt_c = KronWhiten(p_c, lr_params=0.05, lr_preconditioner=0.3)
-    l0 = float(loss_of(p_c))
+    l0 = float(loss_of(p_c).detach())
     for it in range(80):
         opt_c.step(lambda: loss_of(p_c))
-    assert float(loss_of(p_c)) < 0.2 * l0
+    assert float(loss_of(p_c).detach()) < 0.2 * l0
 
 
 def test_kwns4_checkpoint_resume():
