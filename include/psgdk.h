@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 200    /* round 2: PSGDK_MAX_DIMS 8 -> 26 (noise slot arrays), new entry points, PSGDK_ERR_NLB_TIMEOUT */
+#define PSGDK_VERSION 300    /* round 3: test hooks moved to psgdk_test.h, psgdk_test_dump_noise; (200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
 #define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
 
 /* status codes */
@@ -263,44 +263,8 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
 int psgdk_profile_enable(psgdk_plan* plan, int enable);
 int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset);
 
-/* ---- kernel-level test hooks (used by tests/ and bench.py only) ------------------------------------------------
- * C[M,N] = A[M,K] * B[N,K]^T on padded row-major operands (all dims multiples of 64), same kernel the engine uses. */
-/* test hook: ONE norm lower bound (psgd.py:46-93; chain 0 = spd on term1, 1 = skh on R) of every dense factor on the plan's
- * CURRENT work arena (i.e. after a psgdk_update_precond_q0p5eq1p5 call), by the cooperative launch (route 1) or the multi-launch
- * route (route 0), Philox noise (seed, offset).  Copies the four products' row sums of squares ([F][4][32] fp32) to out_vsq and
- * the last two subspace blocks ([F][2][32][max_dense_dim] of the preconditioner dtype: products 4 and 3; rows padded with zeros) to out_v (device
- * pointers, either may be NULL).  inject_fault != 0 makes member 1 of every multi-member factor skip its arrivals, to exercise
- * the timeout path (route 1 only). */
-int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
-                   int inject_fault, void* stream);
-int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int lda,
-                       int ldb, int ldc, int ldct, int symmetric, void* stream);
-/* times `iters` launches of a batch of identical dense problems (contiguous operands) with hipEvents: avg ms/launch */
-int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, float* avg_ms, void* stream);
-int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int flags, void* stream);
-int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int dtype, int M, int N, int K, int batch,
-                          int symmetric, int iters, float* avg_ms, void* stream);
-
-/* X = Y * inv(U) for an upper-triangular U [d x d, row stride ld_u] and Y [rows x d, row stride ld] (the fp32 right
- * solve of psgd.py:288-293), same kernel the EQ update uses; dp = roundup(d, 64) must equal ld_u and ld, buffers padded
- * with zeros to multiples of 64 in both extents.  out_nat [rows_p x dp] and/or out_t [dp x rows_p] (either may be NULL).
- * Ut: NULL -> the fp32-matrix-core kernel (every dtype); U^T [dp x dp] -> the bf16 kernel the EQ update uses for bf16 state
- * (panel resident in LDS, updates on the bf16 matrix cores; dtype must be PSGDK_BF16, dp <= 1088). */
-int psgdk_test_trsm_right(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int dtype, int rows, int d,
-                          void* stream);
-/* Timing of the solve kernels alone (bf16; tools/trsm_bench.py): average of `iters` launches between two events.  Ut as above;
- * dbg (bf16 LDS-panel kernel only): 1 = without the update loop, 2 = without the diagonal step, 4 = without the stores,
- * 8 = 64-row panels (one workgroup per CU) instead of 32-row ones, 16 = the first panel's thread 0 writes shader-clock stamps of
- * its phase boundaries (2 + 4 per 64-column block + 2, int64) into `stamps` (device memory, >= 1 KiB). */
-int psgdk_test_trsm_bench(const void* Y, const void* U, const void* Ut, void* out_nat, void* out_t, int rows, int d, int iters, int dbg,
-                          float* avg_ms, void* stamps, void* stream);
-
-/* Host-only: builds the tile table the grouped GEMM would use for `n` dense problems C[M,N] (K each; sym[i] != 0: upper
- * tiles only) on the 128x128 (big = 0) or 256x256 (big = 1) tiling and reports, per XCD queue, its tile count and its summed
- * cost (K per tile), plus the length of the interleaved table.  No device call: the scheduling rules (queues cut at equal
- * cumulative cost, long tiles first, block b -> XCD b % 8) can be checked without a GPU. */
-int psgdk_test_tile_queues(int n, const int32_t* M, const int32_t* N, const int32_t* K, const int32_t* sym, int big,
-                           int64_t* queue_tiles, int64_t* queue_cost, int64_t* table_len);
+/* Kernel-level test / benchmark hooks (psgdk_test_*) are declared in psgdk_test.h: exported by the same library, not part of the
+ * drop-in surface. */
 
 #ifdef __cplusplus
 }

@@ -541,7 +541,16 @@ class KWNS4Oracle:
                  grad_clip_max_amps=(2.0, 10.0), preconditioner_update_probability=1.0,
                  preconditioner_dtype: Optional[torch.dtype] = torch.bfloat16, update_preconditioner_first=True,
                  uniform: Optional[Callable[[], float]] = None,
-                 noise_for: Optional[Callable[[Tensor, Sequence[str]], KronNoise]] = None, seed: int = 0):
+                 noise_for: Optional[Callable[[Tensor, Sequence[str]], KronNoise]] = None, seed: int = 0,
+                 dQ: str = "Q0.5EQ1.5"):
+        # dQ: the three lines ..._ddp.py:84-86 switched the way KronWhiten switches them (psgd.py:565-586): the update function,
+        # and for the geometries that fit P itself the apply function and the squared initial scale (psgd.py:186-187)
+        self._update = {"Q0.5EQ1.5": update_precond_kron_whiten_q0p5eq1p5, "Q0p5EQ1p5": update_precond_kron_whiten_q0p5eq1p5,
+                        "EQ": update_precond_kron_whiten_eq, "QEQ": update_precond_kron_whiten_qeq,
+                        "QUAD": update_precond_kron_whiten_quad, "QEP": update_precond_kron_whiten_qep,
+                        "QUAD4P": update_precond_kron_whiten_quad4p}[dQ]
+        self._p4 = dQ == "QUAD4P"
+        self._apply = precond_grad_kron_4p if self._p4 else precond_grad_kron
         self.params = params
         self.g = dict(whiten_grad=whiten_grad, preconditioner_max_size=preconditioner_max_size,
                       preconditioner_max_skew=preconditioner_max_skew,
@@ -579,7 +588,7 @@ class KWNS4Oracle:
             if g["preconditioner_dtype"]:
                 grad = grad.to(g["preconditioner_dtype"])
             if len(state) == 0:                                             # ..._ddp.py:129-137
-                state["QL"], state["kinds"] = init_kron(grad, Scale=g["preconditioner_init_scale"],
+                state["QL"], state["kinds"] = init_kron(grad, Scale=g["preconditioner_init_scale"] ** (2 if self._p4 else 1),
                                                         max_size=g["preconditioner_max_size"],
                                                         max_skew=g["preconditioner_max_skew"])
                 state["step"] = 0
@@ -591,20 +600,18 @@ class KWNS4Oracle:
             state["step"] += 1
             to_be_whitened = grad if g["whiten_grad"] else state["ema"]    # ..._ddp.py:145-148
             if first:
-                update_precond_kron_whiten_q0p5eq1p5(state["QL"], to_be_whitened,
-                                                     self._noise_for(to_be_whitened, state["kinds"]),
-                                                     lr=g["lr_preconditioner"], betaL=g["betaL"], damping=g["damping"])
+                self._update(state["QL"], to_be_whitened, self._noise_for(to_be_whitened, state["kinds"]),
+                             lr=g["lr_preconditioner"], betaL=g["betaL"], damping=g["damping"])
             to_be_preconded = grad if momentum == 0.0 else state["ema"]    # ..._ddp.py:150-151
-            h = precond_grad_kron(state["QL"][0], to_be_preconded)
+            h = self._apply(state["QL"][0], to_be_preconded)
             avg_amp = torch.sqrt(torch.mean(h * h))                         # ..._ddp.py:153-157
             if avg_amp > max_avg_amp:
                 h = h * (max_avg_amp / avg_amp)
             h = h.clamp(min=-max_element_amp, max=max_element_amp)
             p.subtract_(h.view_as(p).to(p.dtype), alpha=g["lr_params"])
             if last:                                                        # ..._ddp.py:159-161
-                update_precond_kron_whiten_q0p5eq1p5(state["QL"], to_be_whitened,
-                                                     self._noise_for(to_be_whitened, state["kinds"]),
-                                                     lr=g["lr_preconditioner"], betaL=g["betaL"], damping=g["damping"])
+                self._update(state["QL"], to_be_whitened, self._noise_for(to_be_whitened, state["kinds"]),
+                             lr=g["lr_preconditioner"], betaL=g["betaL"], damping=g["damping"])
 
 
 class KronWhitenOracle:

@@ -12,7 +12,7 @@ BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 200      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 300      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -34,7 +34,7 @@ class Damp(C.Structure):
 
 _lib = None
 
-# name -> (restype, argtypes); every symbol include/psgdk.h declares
+# name -> (restype, argtypes); every symbol include/psgdk.h declares (the drop-in ABI)
 SIGNATURES = {
     "psgdk_version": (C.c_int, []),
     "psgdk_strerror": (C.c_char_p, [C.c_int]),
@@ -96,6 +96,12 @@ SIGNATURES = {
                                            C.c_float, C.c_float, C.c_void_p]),
     "psgdk_lra_last_sumsq": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "psgdk_fill_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+}
+
+# include/psgdk_test.h: kernel-level test / benchmark hooks (same library, not part of the drop-in ABI)
+TEST_SIGNATURES = {
+    "psgdk_test_dump_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "psgdk_test_nlb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -122,7 +128,7 @@ def lib():
                              "(there is no CPU fallback for the HIP engine)")
     import torch  # noqa: F401  (loads libamdhip64.so.7 so the same runtime instance serves both)
     L = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     if L.psgdk_version() != ABI_VERSION:       # a stale libpsgdk.so next to newer Python: its layouts (noise slots per tensor) differ

@@ -60,6 +60,7 @@ struct psgdk_plan {
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
     std::vector<const void*> h_noise_a, h_noise_b;          // staging for explicit-noise pointer tables
+    std::vector<void*> h_dump_g;                            // staging of psgdk_test_dump_noise's output table
     std::vector<int> h_balance;
     std::vector<const void*> h_ptr_a, h_ptr_b;              // what the device tables currently hold (uploads are skipped
                                                             // when a call passes the same addresses as the previous one)
@@ -1520,6 +1521,36 @@ int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t o
     return PSGDK_OK;
 }
 
+int psgdk_test_dump_noise(psgdk_plan* plan, uint64_t seed, uint64_t offset, void* const* g_out, void* const* spd_out,
+                          void* const* skh_out, int pro_iter, void* stream) {
+    if (!plan || pro_iter < -1 || pro_iter > 9) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned F = (unsigned)P->dn.size();
+    if (g_out) {
+        P->h_dump_g.assign(g_out, g_out + P->n_tensors);
+        HIPCHK(hipMemcpyAsync(P->d_noise_g, P->h_dump_g.data(), P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
+        DISPATCH_T(P, hipLaunchKernelGGL(dump_g_noise_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all,
+                                         (void* const*)P->d_noise_g, seed, offset));
+    }
+    if (F && (spd_out || skh_out)) {
+        std::vector<const void*>& a = P->h_noise_a; std::vector<const void*>& b = P->h_noise_b;
+        a.assign(F, nullptr); b.assign(F, nullptr);
+        for (unsigned f = 0; f < F; ++f) {
+            const int slot = P->dn[f].tensor * PSGDK_GEN_MAXDIM + P->dense_dim[f];
+            if (spd_out) a[f] = spd_out[slot];
+            if (skh_out) b[f] = skh_out[slot];
+        }
+        HIPCHK(hipMemcpyAsync(P->d_noise_spd, a.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(P->d_noise_skh, b.data(), F * sizeof(void*), hipMemcpyHostToDevice, st));
+        DISPATCH_T(P, hipLaunchKernelGGL(dump_nlb_noise_kernel<T>, dim3(8, F, 2), dim3(256), 0, st, P->d_dn, (void* const*)P->d_noise_spd,
+                                         (void* const*)P->d_noise_skh, seed, offset, pro_iter));
+    }
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
 int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
                    int inject_fault, void* stream) {
     if (!plan || (chain != 0 && chain != 1) || (route != 0 && route != 1)) return PSGDK_ERR_INVALID;
@@ -1849,7 +1880,10 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
     lra_geometry(N, r, 1, 0, &gb1, &shm1); lra_geometry(N, r, 2, 0, &gb2, &shm2);
     lra_geometry(N, r, 2, 2u * rm * rm * 4u, &gbr, &shmr);                       // the rotation keeps M_u, M_v in LDS as well
     const unsigned shm_s1 = 7u * rm * rm * 4u;
-    HIPCHK(hipMemsetAsync(sm, 0, (size_t)lra_sm_total(tpr) * 4, st));
+    // only the update's own slots: HSQ (||h||^2 of the last psgdk_lra_precond_grad, read by psgdk_flat_apply_clipped) and the apply's
+    // reduction slots behind it survive an update that runs between precond_grad and the clipped parameter update
+    // (update_preconditioner_first=False, psgd.py:1172-1183)
+    HIPCHK(hipMemsetAsync(sm, 0, (size_t)(tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ)) * 4, st));
     LRA_T(L, {
         T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
         T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);

@@ -332,6 +332,27 @@ class KronEngine:
         L.check(self.lib.psgdk_export_precond_grad(self._plan, oa, L.dtype_code(dt), int(clip), float(max_avg_amp), float(max_elem_amp),
                                                    self._stream()), "export_precond_grad")
 
+    @_on_device
+    def dump_noise(self, seed: int, offset: int, pro_iter: int = -1):
+        """TEST hook (psgdk_test_dump_noise, include/psgdk_test.h): what the production noise path draws for (seed, offset) -- the
+        damping noise of every tensor (logical shape) and the two 32 x d start blocks of every dense factor -- in the form
+        update_precond takes as `noise`, so that a test can replay the engine's own Philox draws into the oracle."""
+        g = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.shapes]
+        ga = L.ptr_array(g)
+        sa = (C.c_void_p * (L.MAX_DIMS * self.n))()
+        ka = (C.c_void_p * (L.MAX_DIMS * self.n))()
+        spd, skh = {}, {}
+        for t in range(self.n):
+            for i, kind in enumerate(self.kinds[t]):
+                if kind == L.DENSE:
+                    d = self.Q[t][i].shape[0]
+                    spd[(t, i)] = torch.empty(32, d, dtype=self.dtype, device=self.device)
+                    skh[(t, i)] = torch.empty(32, d, dtype=self.dtype, device=self.device)
+                    sa[t * L.MAX_DIMS + i] = spd[(t, i)].data_ptr()
+                    ka[t * L.MAX_DIMS + i] = skh[(t, i)].data_ptr()
+        L.check(self.lib.psgdk_test_dump_noise(self._plan, int(seed), int(offset), ga, sa, ka, int(pro_iter), self._stream()), "dump_noise")
+        return g, spd, skh
+
     def info(self):
         """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / how often a timeout switched it off."""
         out = {}

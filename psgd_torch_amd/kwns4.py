@@ -27,6 +27,29 @@ from .engine import KronEngine
 from .sharding import chunk_partition, lpt_partition, kron_step_cost
 
 
+_GEOMETRIES = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"}      # psgd.py:161 (init_kron's dQ)
+
+
+def _packed(tensors):
+    """The engine addresses tensors by raw pointer in logical (row-major) order; the reference's `p.subtract_(h.view_as(p))`
+    (..._ddp.py:157) works for any strides.  Non-contiguous tensors (channels_last weights, transposed / tied views) are
+    handed over as a packed row-major shadow; the caller copies the shadows it wrote back with `_unpack`."""
+    out, back = [], []
+    for t in tensors:
+        if t is None or t.is_contiguous():
+            out.append(t)
+        else:
+            sh = t.contiguous()
+            out.append(sh)
+            back.append((t, sh))
+    return out, back
+
+
+def _unpack(back):
+    for t, sh in back:
+        t.copy_(sh)
+
+
 class _Bucket:
     """The parameters of one param_group that share (param dtype, grad dtype): one engine."""
 
@@ -61,6 +84,7 @@ class KWNS4(torch.optim.Optimizer):
             update_preconditioner_first=True,
             resync_every=1000_000,
             *,
+            dQ: str = "Q0.5EQ1.5",
             seed: int = 0,
             shard_state: bool = False,
             shard_chunks: Optional[int] = None,
@@ -106,7 +130,11 @@ class KWNS4(torch.optim.Optimizer):
         }
         super().__init__(params, defaults)
 
-        self.dQ = "Q0.5EQ1.5"
+        # the reference selects the geometry by editing three lines (..._ddp.py:84-86: dQ, update_precond, precond_grad); here it
+        # is a keyword: the engine is built for it (psgd.init_kron's dQ, psgd.py:161) and dispatches update and apply on it
+        if dQ not in _GEOMETRIES:
+            raise NotImplementedError(f"dQ={dQ!r}: built geometries are {sorted(_GEOMETRIES)}")
+        self.dQ = dQ
         self.is_distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.is_distributed else 1
         self.rank = torch.distributed.get_rank() if self.is_distributed else 0
@@ -255,12 +283,14 @@ class KWNS4(torch.optim.Optimizer):
             b.owned = list(range(len(plist)))
         b.shapes = shapes
         if b.owned:
+            p4 = self.dQ in ("QUAD4P", "PRO4P")          # the factors are P itself: init_kron squares the scale (psgd.py:186-187)
+            geom = {} if self.dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5") else {"geometry": self.dQ}
             b.engine = self._engine_factory([shapes[i] for i in b.owned], p0.device, precond_dtype=pd,
                                             max_size=group["preconditioner_max_size"],
                                             max_skew=group["preconditioner_max_skew"],
                                             use_momentum=group["momentum"] > 0.0,
-                                            init_scale=group["preconditioner_init_scale"],   # ..._ddp.py:131-137
-                                            tensor_ids=[(gi << 20) + pos[id(plist[i])] for i in b.owned])
+                                            init_scale=group["preconditioner_init_scale"] ** (2 if p4 else 1),   # ..._ddp.py:131-137
+                                            tensor_ids=[(gi << 20) + pos[id(plist[i])] for i in b.owned], **geom)
             for k, i in enumerate(b.owned):
                 st = self.state[plist[i]]
                 st["QL"] = b.engine.QL(k)
@@ -318,6 +348,15 @@ class KWNS4(torch.optim.Optimizer):
             for b, sub, work in items:
                 self._bucket_finish(b, group, sub, work)
         self._global_step += 1
+        left = getattr(self, "_pending_restore", None)
+        if left and not getattr(self, "_restore_warned", True):
+            # every bucket that exists by now has taken its entry; what is left belongs to buckets this step did not build
+            # (parameters without a gradient so far) -- or to a checkpoint that does not match this optimizer
+            import warnings
+            self._restore_warned = True
+            warnings.warn(f"psgd_torch_amd.KWNS4.load_state_dict: {len(left)} checkpoint bucket(s) have not been matched after the first "
+                          f"step ({sorted(left)[:4]} ...): their preconditioner state is NOT restored yet (parameters without gradients "
+                          "so far, or a checkpoint taken from a different parameter list / sharding)", RuntimeWarning, stacklevel=2)
 
     def _bucket_compute(self, b, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
         wd, lr = group["weight_decay"], group["lr_params"]
@@ -328,7 +367,7 @@ class KWNS4(torch.optim.Optimizer):
         src_p = L.SRC_GRAD if momentum == 0.0 else L.SRC_EMA                          # ..._ddp.py:150
         eng = b.engine
         if eng is not None:
-            own_p = [self._data_of(plist[i]) for i in b.owned]
+            own_p, back = _packed([self._data_of(plist[i]) for i in b.owned])      # (shadows only for strided parameters)
             grads = [self._grad_of(plist[i]) for i in b.owned]
             grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
             coupled = wd if (wd > 0.0 and not decoupled) else 0.0
@@ -344,6 +383,7 @@ class KWNS4(torch.optim.Optimizer):
             eng.precond_grad(src_p)
             if not self.shard_state:
                 eng.apply_update(own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
+                _unpack(back)
             else:
                 # all owned tensors' clipped h straight into this rank's segment of the exchange buffer: one launch
                 eng.export_precond_grad([b.h_views[i] for i in b.owned], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
@@ -368,8 +408,9 @@ class KWNS4(torch.optim.Optimizer):
         if self.shard_state:
             work.wait()
             present = {id(p) for p in plist}
-            lps = [self._data_of(p) if id(p) in present else None for p in b.params]
+            lps, back = _packed([self._data_of(p) if id(p) in present else None for p in b.params])
             b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
+            _unpack(back)
         b.step += 1
         for p in plist:
             self.state[p]["step"] += 1
@@ -390,10 +431,29 @@ class KWNS4(torch.optim.Optimizer):
     # checkpoint / resume.  The reference offers none that works: its state holds opt_einsum expression objects and its
     # private RNG states live outside `state`.  Here the whole engine state of a bucket is one arena
     # tensor (Q, Qt, diagonal factors, L, ema) plus two counters and the host gate generator's state.
-    @staticmethod
-    def _key_str(key) -> str:
-        """Bucket key (group index, param dtype, grad dtype, device[, "p", position]) as a string that survives pickling."""
-        return "|".join(str(x) for x in key)
+    def _single_device(self):
+        """The one device all parameters live on, or None when they span several (then device indices stay in the checkpoint)."""
+        n = sum(len(g["params"]) for g in self.param_groups)
+        c = getattr(self, "_one_dev_cache", None)
+        if c is None or c[0] != n:
+            devs = {self._data_of(p).device for g in self.param_groups for p in g["params"]}
+            c = self._one_dev_cache = (n, next(iter(devs)) if len(devs) == 1 else None)
+        return c[1]
+
+    def _dev_str(self, dev) -> str:
+        """Device as it is written into a checkpoint: the bare TYPE ("cuda") when every parameter of this optimizer lives on one
+        device -- the usual DDP flow is "rank 0 saves, every rank loads", and the bucket of rank r lives on cuda:r --, the full
+        name otherwise."""
+        return dev.type if self._single_device() is not None else str(dev)
+
+    def _dev_from_str(self, s) -> torch.device:
+        one = self._single_device()
+        return one if one is not None else torch.device(s)      # (also reads version-2 files that hold "cuda:0")
+
+    def _key_str(self, key) -> str:
+        """Bucket key (group index, param dtype, grad dtype, device[, "c", chunk][, "p", position]) as a string that survives
+        pickling and does not depend on WHICH GPU of its kind the optimizer lives on."""
+        return "|".join([str(key[0]), str(key[1]), str(key[2]), self._dev_str(key[3])] + [str(x) for x in key[4:]])
 
     def state_dict(self):
         buckets = {}
@@ -412,13 +472,13 @@ class KWNS4(torch.optim.Optimizer):
             start += len(g["params"])
             groups.append(d)
         def parts(k):      # (group, param dtype, grad dtype, device[, "c", chunk][, "p", position]) in a form that survives pickling
-            return [k[0], str(k[1]), str(k[2]), str(k[3])] + list(k[4:])
+            return [k[0], str(k[1]), str(k[2]), self._dev_str(k[3])] + list(k[4:])
         split = [{"key": self._key_str(k), "parts": parts(k), "pd": str(self._split_pd.get(k))} for k in self._split]
         split_owner = [{"parts": parts(k), "owner": list(v)} for k, v in self._split_owner.items()]
         return {"psgdk_version": 2, "state": {},      # per-parameter state lives in the bucket arenas below
                 "param_groups": groups, "split": split, "split_owner": split_owner, "shard_chunks": self._shard_chunks,
                 "chunks": [{"parts": parts(k), "of": dict(v)} for k, v in self._chunks.items()],
-                "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
+                "dQ": self.dQ, "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
 
     def load_state_dict(self, sd):
         """Restores a state_dict() taken from an optimizer over the SAME parameters (same order, shapes, dtypes, sharding).
@@ -439,7 +499,7 @@ class KWNS4(torch.optim.Optimizer):
 
         def _key(parts):
             gi, pdt, gdt, dev = parts[:4]
-            return (int(gi), _dt(pdt), _dt(gdt), torch.device(dev)) + tuple(parts[4:])
+            return (int(gi), _dt(pdt), _dt(gdt), self._dev_from_str(dev)) + tuple(parts[4:])
         for e in sd.get("split_owner", []):
             self._split_owner[_key(e["parts"])] = list(e["owner"])
         for e in sd.get("chunks", []):
@@ -451,7 +511,14 @@ class KWNS4(torch.optim.Optimizer):
                     del self._buckets[key]
                 self._split.add(key)
                 self._split_pd[key] = _dt(e["pd"])
-        self._pending_restore = dict(sd["buckets"])
+        def _norm(ks):        # "gi|pdt|gdt|device|..." with the device re-written the way this optimizer writes it
+            f = ks.split("|")
+            f[3] = self._dev_str(self._dev_from_str(f[3]))
+            return "|".join(f)
+        self._pending_restore = {_norm(k): v for k, v in sd["buckets"].items()}
+        self._restore_warned = False
+        if sd.get("dQ", "Q0.5EQ1.5") != self.dQ:
+            raise ValueError(f"checkpoint was taken with dQ={sd.get('dQ')!r}, this optimizer uses dQ={self.dQ!r}")
         for key, b in self._buckets.items():
             ks = self._key_str(key)
             if ks in self._pending_restore:

@@ -257,9 +257,12 @@ class LRAWhiten:
         if first:
             self._update(target)
         h = precond_grad_lra(self._UVd, self._m if use_m else vec.g)         # psgd.py:1168-1171
-        if last:
-            self._update(target)
+        # The clipped parameter update goes BEFORE a trailing preconditioner update: it reads ||h||^2 from a device word of the
+        # engine that produced h, and on the first step a trailing update re-binds a fresh engine (own scratch block).  The
+        # update reads neither h nor the parameters (psgd.py:1172-1187), so the order does not change any result.
         eng = self._UVd[2]._psgdk_lra
         max_avg_amp, max_element_amp = self.grad_clip_max_amps               # psgd.py:1179-1187, one launch
         vec.apply_clipped(self._params_with_grad, h, self.lr_params, eng.last_sumsq_ptr(), max_avg_amp, max_element_amp)
+        if last:
+            self._update(target)
         return out

@@ -455,8 +455,13 @@ def gen_kron_eq():
 KW_SHAPES = [(48, 32), (32,), (1, 16, 1), (24, 24), (1,), (20, 30)]
 
 
-def gen_kwns4_case(name, T=4, grad_scale=0.3, seed=0, force_gate=None, **kw):
+def gen_kwns4_case(name, T=4, grad_scale=0.3, seed=0, force_gate=None, dQ=None, **kw):
+    """dQ: the reference's own switch -- "one can change these 3 lines to switch the preconditioner"
+    (wrapped_as_torch_optimizer_for_ddp.py:84-86) -- applied to the constructed optimizer the way psgd.KronWhiten makes the
+    same choice (psgd.py:565-586)."""
     out = {"T": np.asarray(T), "nparams": np.asarray(len(KW_SHAPES))}
+    if dQ is not None:
+        out["dQ"] = np.asarray(dQ)
     for k, v in kw.items():
         if k == "preconditioner_dtype":
             out["kw_" + k] = np.asarray({None: "none", torch.bfloat16: "bf16", torch.float32: "fp32"}[v])
@@ -471,6 +476,13 @@ def gen_kwns4_case(name, T=4, grad_scale=0.3, seed=0, force_gate=None, **kw):
         out[f"p{i}_shape"] = np.asarray(p.shape, dtype=np.int64)
     opt = ref_ddp.KWNS4(params, **kw)
     assert not opt.is_distributed
+    if dQ is not None:
+        opt.dQ = dQ
+        opt.update_precond = {"EQ": psgd.update_precond_kron_whiten_eq, "QEQ": psgd.update_precond_kron_whiten_qeq,
+                              "QUAD": psgd.update_precond_kron_whiten_quad, "QEP": psgd.update_precond_kron_whiten_qep,
+                              "QUAD4P": psgd.update_precond_kron_whiten_quad4p}[dQ]
+        if dQ == "QUAD4P":
+            opt.precond_grad = lambda QL, exprs, G: exprs[0](*QL[0], G)
     torch.manual_seed(900 + seed)
     for t in range(T):
         grads = []
@@ -510,6 +522,14 @@ def gen_kwns4():
                    preconditioner_max_skew=float("inf"), force_gate=[0.1, 0.9, 0.2, 0.8, 0.3, 0.7])
     gen_kwns4_case("none_dtype_clip", seed=5, preconditioner_dtype=None, preconditioner_init_scale=10.0,
                    grad_scale=2.0, lr_params=1e-3, grad_clip_max_amps=(1.5, 3.0))
+    # the geometry switch of ..._ddp.py:84-86 (fp32: the factor Q itself is compared for these geometries)
+    gen_kwns4_case("dq_quad_fp32", seed=7, dQ="QUAD", preconditioner_dtype=torch.float32, lr_preconditioner=0.3)
+    gen_kwns4_case("dq_eq_fp32_last", seed=8, dQ="EQ", preconditioner_dtype=torch.float32, lr_preconditioner=0.2,
+                   update_preconditioner_first=False, whiten_grad=True)
+    gen_kwns4_case("dq_qeq_bf16", seed=9, dQ="QEQ", lr_preconditioner=0.3)
+    gen_kwns4_case("dq_quad4p_fp32", seed=10, dQ="QUAD4P", preconditioner_dtype=torch.float32, lr_preconditioner=0.3,
+                   preconditioner_init_scale=0.7)
+    gen_kwns4_case("dq_qep_fp32", seed=11, dQ="QEP", preconditioner_dtype=torch.float32, lr_preconditioner=0.3)
     gen_kwns4_case("fp32_maxsize", seed=6, preconditioner_dtype=torch.float32, preconditioner_max_size=25,
                    preconditioner_max_skew=float("inf"), lr_preconditioner=0.2, betaL=0.8, damping=1e-4)
 
@@ -662,16 +682,15 @@ def gen_lra():
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)
+    # RMS clip engaged (rms(h) ~ 9 x rms(g) > 2) on steps whose update runs AFTER the apply (psgd.py:1172-1183)
+    gen_lrawhiten_case("clip_last_r4", seed=4, rank_of_approximation=4, preconditioner_init_scale=3.0,
+                       update_preconditioner_first=False, lr_params=0.01)
     gen_lrawhiten_case("momentum_r32", seed=3, rank_of_approximation=32, preconditioner_init_scale=1.0, momentum=0.9)
 
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_helpers()
-    gen_kron()
-    gen_kron_eq()
-    gen_kron_geoms()
-    gen_kron_pro4p()
-    gen_kwns4()
-    gen_kronwhiten()
-    gen_lra()
+    groups = {"helpers": gen_helpers, "kron": gen_kron, "kron_eq": gen_kron_eq, "kron_geoms": gen_kron_geoms,
+              "kron_pro4p": gen_kron_pro4p, "kwns4": gen_kwns4, "kronwhiten": gen_kronwhiten, "lra": gen_lra}
+    for name in (sys.argv[1:] or list(groups)):       # no argument: everything
+        groups[name]()

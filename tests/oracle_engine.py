@@ -32,7 +32,12 @@ class OracleEngine:
     FlatApply = _TorchFlatApply
 
     def __init__(self, shapes, device, precond_dtype=torch.bfloat16, max_size=float("inf"), max_skew=1.0,
-                 use_momentum=True, init_scale=1.0, tensor_ids=None):
+                 use_momentum=True, init_scale=1.0, tensor_ids=None, geometry="Q0.5EQ1.5"):
+        self.geometry = geometry
+        self._update = {"Q0.5EQ1.5": orc.update_precond_kron_whiten_q0p5eq1p5, "EQ": orc.update_precond_kron_whiten_eq,
+                        "QEQ": orc.update_precond_kron_whiten_qeq, "QUAD": orc.update_precond_kron_whiten_quad,
+                        "QEP": orc.update_precond_kron_whiten_qep, "QUAD4P": orc.update_precond_kron_whiten_quad4p}[geometry]
+        self._apply = orc.precond_grad_kron_4p if geometry == "QUAD4P" else orc.precond_grad_kron
         self.shapes = [tuple(s) for s in shapes]
         self.n = len(self.shapes)
         self.dtype = precond_dtype
@@ -91,11 +96,11 @@ class OracleEngine:
             G = self._src(source, k)
             nz = orc.KronNoise.draw(G, self.kinds[k], self._gen(seed, offset, self.ids[k]))
             nz.balance_u = 0.0 if (balance_mask is not None and balance_mask[k]) else 1.0
-            orc.update_precond_kron_whiten_q0p5eq1p5(self.QLs[k], G, nz, lr=lr, betaL=betaL, damping=damping)
+            self._update(self.QLs[k], G, nz, lr=lr, betaL=betaL, damping=damping)
 
     def precond_grad(self, source):
         for k in range(self.n):
-            self.h[k] = orc.precond_grad_kron(self.QLs[k][0], self._src(source, k))
+            self.h[k] = self._apply(self.QLs[k][0], self._src(source, k))
 
     def _clipped(self, k, max_avg_amp, max_elem_amp):
         h = self.h[k]

@@ -20,8 +20,8 @@ def lib():
     return _lib.lib()
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "psgdk.h")).read()
+def _declared_functions(header="psgdk.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(psgdk_[a-z0-9_]+)\s*\(", text)))
 
@@ -33,6 +33,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/psgdk.h but not exported by libpsgdk.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in psgd_torch_amd/_lib.py"
+        assert not n.startswith("psgdk_test_"), f"{n}: test hooks belong in include/psgdk_test.h, not in the drop-in header"
+    assert set(_lib.SIGNATURES) == set(names), "ctypes signatures without a declaration in include/psgdk.h"
+    hooks = _declared_functions("psgdk_test.h")
+    assert hooks and all(n.startswith("psgdk_test_") for n in hooks), hooks
+    for n in hooks:
+        assert hasattr(lib, n), f"{n} declared in include/psgdk_test.h but not exported by libpsgdk.so"
+        assert n in _lib.TEST_SIGNATURES, f"{n} has no ctypes signature in psgd_torch_amd/_lib.py"
+    assert set(_lib.TEST_SIGNATURES) == set(hooks)
     assert lib.psgdk_version() >= 100
     assert lib.psgdk_strerror(1) == b"invalid argument"
 

@@ -140,8 +140,10 @@ def test_functional_seam_vs_golden(name, force_big, monkeypatch):
                     assert e_hip <= 1.5 * e_ref + floor, (name, dn, t, what, e_hip, e_ref)
 
 
-def _parse_step_draws(z, t, kinds_per_tensor, shapes):
-    """Splits the reference's recorded draw stream of one KWNS4.step into (gate_u, [per-tensor dict] or None)."""
+def _parse_step_draws(z, t, kinds_per_tensor, shapes, dQ="Q0.5EQ1.5"):
+    """Splits the reference's recorded draw stream of one KWNS4.step into (gate_u, [per-tensor dict] or None).  Only the default
+    geometry draws a second 32 x d block per dense factor (procrustes_step2, psgd.py:87); QEP has no balancing gate."""
+    has_skh, has_gate = dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5"), dQ != "QEP"
     nd = int(z[f"t{t}_ndraws"])
     k = 0
     gate = float(z[f"t{t}_draw0"]); k += 1
@@ -153,8 +155,12 @@ def _parse_step_draws(z, t, kinds_per_tensor, shapes):
         d["spd"], d["skh"] = {}, {}
         for i, kind in enumerate(kinds):
             if kind == "dense":
-                d["spd"][i] = z[f"t{t}_draw{k}"]; d["skh"][i] = z[f"t{t}_draw{k + 1}"]; k += 2
-        d["u"] = float(z[f"t{t}_draw{k}"]); k += 1
+                d["spd"][i] = z[f"t{t}_draw{k}"]; k += 1
+                if has_skh:
+                    d["skh"][i] = z[f"t{t}_draw{k}"]; k += 1
+        d["u"] = 1.0
+        if has_gate:
+            d["u"] = float(z[f"t{t}_draw{k}"]); k += 1
         per.append(d)
     assert k == nd
     return gate, per
@@ -166,12 +172,15 @@ def test_kwns4_step_vs_golden(name):
     from test_oracle_golden import _kw_from_golden
     z = load(name)
     kw = _kw_from_golden(z)
+    dQ = str(z["dQ"]) if "dQ" in z.files else "Q0.5EQ1.5"      # fixtures recorded with ..._ddp.py:84-86 switched (kwns4_dq_*)
     n, Tn = int(z["nparams"]), int(z["T"])
     params = [torch.nn.Parameter(T(z[f"p{i}_init"], torch.float32).to(DEV)) for i in range(n)]
     pd = kw.get("preconditioner_dtype", torch.bfloat16)
     dn = "bf16" if pd == torch.bfloat16 else "fp32"
     dt = DT[dn]
-    opt = amd.KWNS4(params, **kw)
+    opt = amd.KWNS4(params, dQ=dQ, **kw)
+    # the factors of QUAD4P ARE P (psgd.py:486-513); every other non-default geometry has no gauge freedom, so Q itself is compared
+    P_of = (lambda qs: [torch.as_tensor(q).detach().cpu().double() for q in qs]) if dQ != "Q0.5EQ1.5" else globals()["P_of"]
     shapes = [tuple(p.squeeze().shape) for p in params]
     kinds = [orc.kron_factor_kinds(s, kw.get("preconditioner_max_size", float("inf")), kw.get("preconditioner_max_skew", 1.0))
              for s in shapes]
@@ -180,9 +189,9 @@ def test_kwns4_step_vs_golden(name):
     p64 = [T(z[f"p{i}_init"], torch.float64).clone() for i in range(n)]
     kw64 = dict(kw); kw64["preconditioner_dtype"] = torch.float64
     cur = {}
-    o64 = orc.KWNS4Oracle(p64, uniform=lambda: cur["r"].uniform(), noise_for=lambda G, k_: cur["r"].noise_for(G, k_), **kw64)
+    o64 = orc.KWNS4Oracle(p64, uniform=lambda: cur["r"].uniform(), noise_for=lambda G, k_: cur["r"].noise_for(G, k_), dQ=dQ, **kw64)
     for t in range(Tn):
-        gate, per = _parse_step_draws(z, t, kinds, shapes)
+        gate, per = _parse_step_draws(z, t, kinds, shapes, dQ)
         gates = iter([gate])
         opt._uniform = lambda: next(gates)
 
@@ -195,7 +204,7 @@ def test_kwns4_step_vs_golden(name):
         for i in range(n):
             params[i].grad = T(z[f"t{t}_g{i}"], torch.float32).to(DEV)
         opt.step()
-        cur["r"] = DrawReplay(z, t)
+        cur["r"] = DrawReplay(z, t, dQ)
         o64.step([T(z[f"t{t}_g{i}"], torch.float64) for i in range(n)])
         for i in range(n):
             gold_p = z[f"t{t}_p{i}"]

@@ -144,6 +144,8 @@ def _kw_from_golden(z):
         name = k[3:]
         if name == "preconditioner_dtype":
             kw[name] = {"none": None, "bf16": torch.bfloat16, "fp32": torch.float32}[str(v)]
+        elif name == "dQ":
+            kw[name] = str(v)
         elif name == "grad_clip_max_amps":
             kw[name] = tuple(float(x) for x in v)
         elif v.dtype == np.bool_:
@@ -156,9 +158,13 @@ def _kw_from_golden(z):
 class DrawReplay:
     """Replays the reference's recorded draw stream of one KWNS4.step (SURVEY 8c draw order)."""
 
-    def __init__(self, z, t):
+    def __init__(self, z, t, dQ="Q0.5EQ1.5"):
         self.z, self.t, self.k = z, t, 0
         self.n = int(z[f"t{t}_ndraws"])
+        # only the default geometry rotates (procrustes_step2 -> a second 32 x d draw per dense factor, psgd.py:87); QEP has no
+        # balancing gate (it balances on every call, psgd.py:346-347)
+        self.has_skh = dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5")
+        self.has_gate = dQ != "QEP"
 
     def _next(self, kind):
         assert self.k < self.n, "oracle consumed more draws than the reference made"
@@ -176,26 +182,27 @@ class DrawReplay:
         for kind in kinds:
             if kind == "dense":
                 spd.append(T(self._next("randn"), G.dtype))
-                skh.append(T(self._next("randn"), G.dtype))
+                skh.append(T(self._next("randn"), G.dtype) if self.has_skh else None)
             else:
                 spd.append(None)
                 skh.append(None)
-        return orc.KronNoise(g_noise, spd, skh, float(self._next("rand")))
+        return orc.KronNoise(g_noise, spd, skh, float(self._next("rand")) if self.has_gate else 1.0)
 
 
 @pytest.mark.parametrize("name", golden_names("kwns4_"))
 def test_kwns4_step(name):
     z = load(name)
     kw = _kw_from_golden(z)
+    dQ = str(z["dQ"]) if "dQ" in z.files else "Q0.5EQ1.5"      # fixtures recorded with ..._ddp.py:84-86 switched
     n, Tn = int(z["nparams"]), int(z["T"])
     params = [T(z[f"p{i}_init"], torch.float32).clone() for i in range(n)]
     pd = kw.get("preconditioner_dtype", torch.bfloat16)
     dn = "bf16" if pd == torch.bfloat16 else "fp32"
     replay = {"cur": None}
     opt = orc.KWNS4Oracle(params, uniform=lambda: replay["cur"].uniform(),
-                          noise_for=lambda G, kinds: replay["cur"].noise_for(G, kinds), **kw)
+                          noise_for=lambda G, kinds: replay["cur"].noise_for(G, kinds), dQ=dQ, **kw)
     for t in range(Tn):
-        replay["cur"] = DrawReplay(z, t)
+        replay["cur"] = DrawReplay(z, t, dQ)
         grads = [T(z[f"t{t}_g{i}"], torch.float32) for i in range(n)]
         opt.step(grads)
         assert replay["cur"].k == replay["cur"].n, "draw count differs from the reference"
