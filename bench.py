@@ -13,8 +13,11 @@ Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
                   it (SURVEY 8d model: 905.2 GFLOP per step, minus the 2 x 256 d^2 of the two norm bounds when the cooperative
                   kernel runs them = 886.5 GFLOP in 9 launches) / their launch time measured live with hipEvents on the launch
                   stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
-  cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on a bounded sample: ONE of the
-                  12 transformer blocks, at all host threads and at 8 threads; the whole-model figure is an extrapolation.
+                  `peak_measured` holds this chip's own ceilings (MFMA loops of both bf16 shapes on register operands, a streaming
+                  copy and read), measured in-process after the timed region;
+  cpu_baseline -- the CPU oracle (a port, test infrastructure) timed on this box's host cores on the WHOLE workload (all 148
+                  tensors), at 8 threads and at the physical cores of one socket.
+The synthetic gradients are the structured variant of SURVEY 8d (g = H1 V H2) unless --gaussian-grads.
 After the timed region every parameter and the whole preconditioner state are checked to be finite (a fast wrong step is not
 a measurement).
 """
@@ -69,50 +72,78 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(seconds_budget=9.0):
-    """The CPU oracle (oracle/psgd_oracle.py, a port of the reference path) on ONE GPT-2-small transformer block
-    (12 tensors, 7,087,872 params = 1/17.6 of the model; 58 of the step's 905 GFLOP), bf16 preconditioner, same
-    hyper-parameters, at two thread counts: every host thread torch will use, and 8 (comparable with the survey
-    container's probe of the reference itself, BASELINE.md section 2: 0.23-0.28 s per block).  Bounded to ~2 x seconds_budget.
-    `value` is the block's own rate at the FASTER of the two thread counts (`cores` says which); the whole-model step is an
-    extrapolation by the FLOP model (wte alone is another ~20 %), not a measurement."""
-    from oracle import psgd_oracle as orc
-    shapes = gpt2_shapes()[2:14]
-    nparam = sum(math.prod(s) for s in shapes)
-    n_all = torch.get_num_threads()
+def _physical_cores_of_one_socket():
+    """(physical cores of socket 0, number of sockets) from /proc/cpuinfo; (None, None) if it cannot be read."""
+    try:
+        phys, cores = set(), {}
+        cur = {}
+        for line in list(open("/proc/cpuinfo")) + ["\n"]:
+            if line.strip() == "":
+                if "physical id" in cur:
+                    phys.add(cur["physical id"])
+                    cores.setdefault(cur["physical id"], set()).add(cur.get("core id", len(cores.get(cur["physical id"], ()))))
+                cur = {}
+                continue
+            k, _, v = line.partition(":")
+            cur[k.strip()] = v.strip()
+        if not phys:
+            return None, None
+        return len(cores[sorted(phys)[0]]), len(phys)
+    except OSError:
+        return None, None
 
-    def run(threads):
+
+def cpu_baseline(block_budget=2.5):
+    """The CPU oracle (oracle/psgd_oracle.py, a port of the reference path, test infrastructure) timed on this box's host cores on
+    the WHOLE workload: the identical KWNS4.step over all 148 GPT-2-small tensors (124,475,904 parameters, wte included), bf16
+    preconditioner, same hyper-parameters, synthetic gradients -- SURVEY 8d.  Two thread counts: 8 (comparable with the survey
+    container's probe of the reference itself) and the physical cores of one socket; one untimed step (state
+    initialisation) and then 3 / 2 timed steps, about 10-25 s of CPU work in all.  `value` is the faster of the two (`cores` says
+    which).  A short sample of ONE transformer block is kept as a secondary field (comparable with rounds 1-2)."""
+    from oracle import psgd_oracle as orc
+    shapes_all = gpt2_shapes()
+    n_all = torch.get_num_threads()
+    socket_cores, n_sockets = _physical_cores_of_one_socket()
+    if not socket_cores:
+        socket_cores = n_all
+
+    def run(shapes, threads, timed_steps, budget=None):
         torch.set_num_threads(threads)
         gen = torch.Generator().manual_seed(0)
         params = [0.02 * torch.randn(*s, generator=gen) for s in shapes]
         opt = orc.KWNS4Oracle(params, seed=0)
         times = []
         t_all = time.time()
-        for it in range(50):
+        for it in range(1 + timed_steps):
             grads = [0.01 * torch.randn(*s, generator=gen) for s in shapes]
             t0 = time.time()
             opt.step(grads)
             times.append(time.time() - t0)
-            if it >= 2 and time.time() - t_all > seconds_budget:
+            if budget is not None and it >= 2 and time.time() - t_all > budget:
                 break
-        return sorted(times[1:])[len(times[1:]) // 2], len(times) - 1
+        t = sorted(times[1:])
+        return t[len(t) // 2], len(t)
+    nparam = sum(math.prod(s) for s in shapes_all)
+    full_step_flops, _ = flop_model(shapes_all)
     try:
-        s_all, k_all = run(n_all)
-        s_8, k_8 = run(min(8, n_all))
+        s8, k8 = run(shapes_all, min(8, n_all), 3)
+        ss, ks = (s8, k8) if socket_cores == min(8, n_all) else run(shapes_all, min(socket_cores, n_all), 2)
+        blk = shapes_all[2:14]
+        b8, kb8 = run(blk, min(8, n_all), 30, budget=block_budget)
     finally:
         torch.set_num_threads(n_all)
-    full_step_flops, _ = flop_model(gpt2_shapes())
-    block_flops, _ = flop_model(shapes)
-    best, cores = (s_all, n_all) if s_all <= s_8 else (s_8, min(8, n_all))     # (128 oversubscribed threads lose to 8 on one block)
+    best, cores = (s8, min(8, n_all)) if s8 <= ss else (ss, min(socket_cores, n_all))
+    blk_flops, _ = flop_model(blk)
     return {"value": nparam / best / 1e9, "unit": "Gparam/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "ms_per_block_step": best * 1e3, "gflops": block_flops / best / 1e9,
-            "all_threads": {"value": nparam / s_all / 1e9, "ms_per_block_step": s_all * 1e3, "gflops": block_flops / s_all / 1e9, "cores": n_all},
-            "threads8": {"value": nparam / s_8 / 1e9, "ms_per_block_step": s_8 * 1e3, "gflops": block_flops / s_8 / 1e9, "cores": min(8, n_all)},
-            "extrapolated_full_step_s": {"all_threads": s_all * full_step_flops / block_flops, "threads8": s_8 * full_step_flops / block_flops},
-            "sample": f"ONE of 12 GPT-2-small transformer blocks (12 tensors, {nparam} params, {block_flops / 1e9:.0f} of the step's "
-                      f"{full_step_flops / 1e9:.0f} GFLOP), bf16 preconditioner; median of {k_all} steps at {n_all} threads "
-                      f"({s_all * 1e3:.0f} ms) and of {k_8} steps at 8 threads ({s_8 * 1e3:.0f} ms); whole-model figures are "
-                      "extrapolated by the FLOP model, not measured; baseline only"}
+            "s_per_step": best, "gflops": full_step_flops / best / 1e9,
+            "threads8": {"value": nparam / s8 / 1e9, "s_per_step": s8, "gflops": full_step_flops / s8 / 1e9, "cores": min(8, n_all), "timed_steps": k8},
+            "one_socket": {"value": nparam / ss / 1e9, "s_per_step": ss, "gflops": full_step_flops / ss / 1e9,
+                           "cores": min(socket_cores, n_all), "sockets_on_box": n_sockets, "timed_steps": ks},
+            "block_sample_threads8": {"ms_per_block_step": b8 * 1e3, "gflops": blk_flops / b8 / 1e9, "timed_steps": kb8,
+                                      "what": "ONE of the 12 transformer blocks (12 tensors), as rounds 1-2 timed it"},
+            "sample": f"the WHOLE GPT-2-small step: KWNS4Oracle.step over all 148 tensors ({nparam} params, {full_step_flops / 1e9:.0f} GFLOP), "
+                      f"bf16 preconditioner; median of {k8} steps at 8 threads ({s8:.2f} s) and of {ks} steps at {min(socket_cores, n_all)} threads = the "
+                      f"physical cores of one socket ({ss:.2f} s), one untimed initialisation step before each; baseline only"}
 
 
 def bench_lra(args):
@@ -229,6 +260,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="do not time the GEMM launches with hipEvents (no roofline "
                                                                "object; shows what the event pairs cost the step)")
     ap.add_argument("--no-apply-only", action="store_true", help="skip the secondary apply-only measurement (profiling runs)")
+    ap.add_argument("--gaussian-grads", action="store_true", help="white-noise gradients 0.01 N(0,1) instead of the structured "
+                                                                  "g = H1 V H2 (SPD H, condition ~1e3: SURVEY 8d) the headline uses, "
+                                                                  "under which the preconditioner actually moves while timed")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the in-process ceiling measurement (roofline.peak_measured)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
@@ -278,7 +313,19 @@ def main():
     pd = torch.float32 if args.fp32 else torch.bfloat16
     # synthetic gradient streams resident in HBM: a few distinct draws, cycled
     n_sets = 2
-    grad_sets = [[0.01 * torch.randn(*s, device=dev, generator=gen) for s in shapes] for _ in range(n_sets)]
+
+    def synth_grad(shp):
+        v = torch.randn(*shp, device=dev, generator=gen)
+        if args.gaussian_grads or len(shp) != 2:
+            return 0.01 * v
+        # g = H1 V H2 with diagonal-in-a-random-basis-free SPD factors: per-row and per-column scales spread log-uniformly over
+        # 1.5 decades each (condition ~1e3 of H1 (x) H2), shuffled; normalised to the same RMS as the white-noise variant
+        m, n = shp
+        sm = torch.logspace(0, -1.5, m, device=dev)[torch.randperm(m, device=dev, generator=gen)]
+        sn = torch.logspace(0, -1.5, n, device=dev)[torch.randperm(n, device=dev, generator=gen)]
+        g = sm[:, None] * v * sn[None, :]
+        return g * (0.01 / g.square().mean().sqrt())
+    grad_sets = [[synth_grad(s) for s in shapes] for _ in range(n_sets)]
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -310,7 +357,7 @@ def main():
     if dist and args.parallelism != "sharded":
         mode = "replicated"
     if dist and args.parallelism == "auto":
-        timing = {}
+        timing, failures = {}, []
         for name in ("sharded", "sharded, one exchange", "replicated"):
             # (a mode that raises -- e.g. a collective the installed RCCL / torch refuses -- is dropped from the probe on every rank
             #  alike: argument errors are deterministic; the timed region then runs with what is left)
@@ -327,13 +374,17 @@ def main():
                 el = time.perf_counter() - t_
                 del ps_, o_, f_
             except Exception as e:      # noqa: BLE001
-                if rank == 0:
-                    print(f"bench: mode {name!r} failed in the probe: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                print(f"bench: rank {rank}: mode {name!r} failed in the probe: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                failures.append(f"{name}: {type(e).__name__}: {e}")
                 el = float("inf")
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            # the failed flag travels with the time, in the FIRST collective after the try block: a failure on one rank only (out of
+            # memory, a transport error) marks the mode as failed everywhere
+            tt = torch.tensor([el if math.isfinite(el) else 1e300], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            timing[name] = float(tt.item()) / 4
+            timing[name] = float(tt.item()) / 4 if float(tt.item()) < 1e299 else float("inf")
             torch.cuda.empty_cache()
+        if not any(math.isfinite(v) for v in timing.values()):
+            raise SystemExit("bench.py: every parallelism mode failed in the warm-up probe: " + "; ".join(failures or ["(on another rank)"]))
         mode = min(timing, key=timing.get)
     params, opt = make(mode)
     one_step = step_of(params, opt)
@@ -422,7 +473,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "fp32" if args.fp32 else "bf16",
-        "data": "synthetic",
+        "data": "synthetic" + (" (white-noise gradients)" if args.gaussian_grads else " (structured gradients g = H1 V H2, SURVEY 8d)"),
         "config": {"workload": {"gpt2-small": "GPT-2-small parameter shapes (misc/gpt2.py GPTConfig defaults): 148 tensors, "
                                               f"{nparam} params, 62 dense 768x768 Kron factors",
                                 "gpt2-medium": f"GPT-2-medium parameter shapes (24 layers, d=1024): {len(shapes)} tensors, {nparam} params",
@@ -454,14 +505,37 @@ def main():
                 traffic = (tj.get("gemm_all_tilings") or tj["kernels"]["gemm_nt_kernelIt"])["hbm_bytes_per_launch_corrected"]
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_nt_big_kernel <bf16> (all grouped-GEMM launches of the step)"
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_nt_pipe_kernel <bf16> (all grouped-GEMM launches of the step: the "
+                                                      "128 x 128 tiling and the persistent 256 x 256 one)"
                            if not args.fp32 else "gemm_nt_kernel<float>",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                           "traffic": traffic, "launches_per_step": launches_per_step,
+                           "traffic": traffic,
+                           "traffic_source": ("profiles/pmc_traffic_latest.json: separate rocprofv3 --pmc passes of this command on this "
+                                              "code (FETCH_SIZE x 2 + WRITE_SIZE per launch); counters cannot be read in-process")
+                           if traffic is not None else None,
+                           "launches_per_step": launches_per_step,
                            "avg_launch_us": avg_launch_s * 1e6,
                            "algorithmic_gflop_per_launch": gemm_flops / launches_per_step / 1e9,
                            "gemm_ms_per_step": gemm_ms / prof_steps, "steps_with_events": prof_steps,
                            "whole_step_frac_of_peak": step_flops / (dt / args.steps) / 1e12 / peak}
+    if world == 1 and "roofline" in out and not args.no_peaks:
+        # ceilings of THIS chip, measured in-process in < 1 s (SURVEY 8d "re-verify on the box"): register-operand MFMA loops of both
+        # bf16 shapes, a streaming copy and a streaming read of 1 GiB
+        import ctypes as C
+        from psgd_torch_amd import _lib
+        scratch = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+        scratch.random_(0, 255)
+        pk = (C.c_float * 4)()
+        _lib.check(_lib.lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
+        del scratch
+        r = out["roofline"]
+        r["peak_measured"] = {"mfma_16x16x32_bf16_tflops": pk[0], "mfma_32x32x16_bf16_tflops": pk[1], "hbm_copy_gbs": pk[2],
+                              "hbm_read_gbs": pk[3],
+                              "what": "register-operand MFMA loops (2 waves per SIMD, 16 / 4 independent accumulator chains) and a "
+                                      "streaming 16-byte copy / read of 1 GiB, best of 3, measured in this process after the timed region"}
+        if not args.fp32:
+            r["frac_of_measured_mfma"] = r["achieved"] / max(pk[0], pk[1])
+            r["whole_step_frac_of_measured_mfma"] = r["whole_step_frac_of_peak"] * peak / max(pk[0], pk[1])
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and run_cpu:
             out["cpu_baseline"] = cpu_baseline()

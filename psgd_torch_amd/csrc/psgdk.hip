@@ -10,6 +10,7 @@
 #include "kernels_lra.hiph"
 #include "kernels_gen.hiph"
 #include "kernels_eq.hiph"
+#include "kernels_probe.hiph"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -58,12 +59,11 @@ struct psgdk_plan {
     EwTile* d_tiles_all = nullptr; unsigned n_tiles_all = 0;
     std::vector<unsigned> tile_begin;                // per tensor range in d_tiles_all
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
-    void** d_ptr_a = nullptr; void** d_ptr_b = nullptr;     // n_tensors pointers each
+    PtrTableCache ptrs_a, ptrs_b;                           // device copies of the callers' pointer tables (gradients; parameters / outputs)
+    bool zero_clean = false, hsq_clean = false;             // psgdk_accumulate zeroed the update's accumulators / the sums of h^2 in its own pass
     std::vector<const void*> h_noise_a, h_noise_b;          // staging for explicit-noise pointer tables
     std::vector<void*> h_dump_g;                            // staging of psgdk_test_dump_noise's output table
     std::vector<int> h_balance;
-    std::vector<const void*> h_ptr_a, h_ptr_b;              // what the device tables currently hold (uploads are skipped
-                                                            // when a call passes the same addresses as the previous one)
     void** d_noise_g = nullptr; void** d_noise_spd = nullptr; void** d_noise_skh = nullptr;
     float* d_scale_diag = nullptr; float* d_scale_dense = nullptr;
     int* d_balance = nullptr;
@@ -83,6 +83,10 @@ struct psgdk_plan {
     // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
     bool p_mode() const { return geometry == PSGDK_GEOM_QUAD4P || geometry == PSGDK_GEOM_PRO4P; }   // the factors ARE P (psgd.py:422-452, 486-513)
+    // default geometry: the update + Procrustes chain runs in transposed space (see psgdk_plan_bind); PSGDK_CHAIN=legacy keeps the
+    // round-2 Q-space chain (A/B runs and the bit-for-bit comparison of the two)
+    bool chain_legacy = false;
+    bool chain_t() const { return geometry == PSGDK_GEOM_Q0P5EQ1P5 && !chain_legacy; }
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
     Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
     Stage v_qep_u, v_qep_t1, v_qep_t2;               // PSGDK_GEOM_QEP: Q term1, (Q term1) Q^T, c Q Q^T
@@ -105,7 +109,7 @@ struct psgdk_plan {
 
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
-        fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag); fr(d_ptr_a); fr(d_ptr_b);
+        fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag);
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
@@ -330,6 +334,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->esz = precond_dtype == PSGDK_BF16 ? 2 : 4;
     P->max_size = max_size; P->max_skew = max_skew;
     { const char* e = getenv("PSGDK_NLB_FUSED"); P->nlb_unfused = e && e[0] == '0'; }
+    { const char* e = getenv("PSGDK_CHAIN"); P->chain_legacy = e && e[0] == 'l'; }
     size_t dpos = 0;
     // ---- structure (init_kron's dense/diag rule) ----
     for (int t = 0; t < n_tensors; ++t) {
@@ -535,8 +540,6 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(void*)));
         return PSGDK_OK;
     };
-    if ((rc = alloc_ptrs(&P->d_ptr_a, P->n_tensors))) return rc;
-    if ((rc = alloc_ptrs(&P->d_ptr_b, P->n_tensors))) return rc;
     if ((rc = alloc_ptrs(&P->d_noise_g, P->n_tensors))) return rc;
     if ((rc = alloc_ptrs(&P->d_noise_spd, P->dn.size()))) return rc;
     if ((rc = alloc_ptrs(&P->d_noise_skh, P->dn.size()))) return rc;
@@ -590,6 +593,34 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 if (p & 1) { g.row_scale = vsq - 64; g.flags = GF_RSQRT_ROWSCALE; }
                 P->g_nlb[chain][p].probs.push_back(g);
             }
+        if (P->chain_t()) {
+            // The Q0.5EQ1.5 update + procrustes_step2 in TRANSPOSED space (round 3): with T = term1 symmetric and R antisymmetric, every
+            // product of psgd.py:415 and :117-124 has an NT form that needs only the transposes Z = Q'^T, RQ^T, and R itself:
+            //   Z     = Qt - mu (Qt T - c Qt)         NT(A = Qt,   B = T)        = (T Q)^T                   [one output]
+            //   R     = Z - Z^T                        rsub_t_kernel (reads Z only)
+            //   RQ^T  = s NT(A = Z,    B = R)          (R Q')[n][m] = sum_k R[n][k] Z[m][k]                  [one output]
+            //   Qt   <- Z + a (RQ^T + a/2 RRQ^T),      RRQ^T = s NT(A = RQ^T, B = R): (R RQ)[n][m] = sum_k R[n][k] RQ^T[m][k]
+            //           stored as Qt (primary) and Q (transposed copy), straight into the state.
+            // Each accumulator sums the same products in the same K order as the Q-space form (operands swapped), so every output is
+            // bit-identical to it; the stages read and write 3 / 3 / 4.5 of a factor's matrices where they moved 5 / 5 / 6 (Q', RQ
+            // and the second copy of every intermediate are gone: 1.39 -> 0.99 GB per GPT-2-small step over the chain).
+            g = GemmProblem{};
+            g.A = S + F.qt_off; g.B = W + F.t1_off; g.C = W + F.qtn_off; g.Ct = nullptr;
+            g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = g.ldq = F.dp; g.alpha = 1.f;
+            g.flags = GF_QUPD; g.Qold = S + F.qt_off; g.mu_dev = sc + DS_MU; g.c = F.c;
+            P->g_qupd.probs.push_back(g);
+            g = GemmProblem{};
+            g.A = W + F.qtn_off; g.B = W + F.r_off; g.C = W + F.rqt_off; g.Ct = nullptr;
+            g.M = g.N = g.K = F.dp; g.lda = g.ldb = g.ldc = g.ldct = F.dp; g.alpha = 1.f; g.alpha_dev = sc + DS_S; g.trace = sc + DS_TR1;
+            // tr(R RQ) = <R, RQ^T>: available from THIS product's epilogue, before R RQ is formed
+            g.dot_with = W + F.r_off; g.lddot = F.dp; g.dot_out = sc + DS_TR2; g.flags = GF_DOT_POS;
+            P->g_rq.probs.push_back(g);
+            g.dot_with = nullptr; g.dot_out = nullptr; g.trace = nullptr;
+            g.A = W + F.rqt_off; g.B = W + F.r_off; g.C = S + F.qt_off; g.Ct = S + F.q_off;
+            g.flags = GF_PROCR; g.X1 = W + F.qtn_off; g.X2 = W + F.rqt_off; g.ldq = F.dp; g.tr1_dev = sc + DS_TR1; g.tr2_dev = sc + DS_TR2;
+            P->g_rrq.probs.push_back(g);
+            continue;
+        }
         // Q' = Q - mu (term1 Q - c Q)   (psgd.py:415)
         g = GemmProblem{};
         g.A = W + F.t1_off; g.B = S + F.qt_off; g.C = W + F.qn_off; g.Ct = W + F.qtn_off;
@@ -876,8 +907,9 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     for (int t = 0; t < plan->n_tensors; ++t) if (!grads[t] || (coupled_wd != 0.f && !params[t])) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     int rcp;
-    if ((rcp = upload_ptrs(plan->d_ptr_a, plan->h_ptr_a, grads, plan->n_tensors, st))) return rcp;
-    if (coupled_wd != 0.f && (rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)params, plan->n_tensors, st))) return rcp;
+    void** d_grads = nullptr; void** d_params = nullptr;
+    if ((rcp = plan->ptrs_a.get(grads, plan->n_tensors, st, &d_grads))) return rcp;
+    if (coupled_wd != 0.f && (rcp = plan->ptrs_b.get((const void* const*)params, plan->n_tensors, st, &d_params))) return rcp;
     const int keep = (keep_grad || !plan->use_momentum) ? 1 : 0;
     // optional fusion of the update's damped input X (psgd.py:402-403) into this pass (saves one read of the source)
     plan->x_valid = false;
@@ -895,10 +927,16 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
         do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
     }
     DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
-                                        plan->d_tiles_all, (const void* const*)plan->d_ptr_a, (const void* const*)plan->d_ptr_b,
+                                        plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,
                                         plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
-                                        do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0));
+                                        do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0,
+                                        (unsigned long long)plan->hsumsq_off, (unsigned)plan->n_tensors,
+                                        (unsigned long long)plan->zero_off, (unsigned long long)(damp ? plan->zero_bytes : 0)));
     HIPCHK(hipGetLastError());
+    // this pass also cleared the sums of h^2 (the precond_grad of this step) and, when an update was announced, that update's
+    // accumulators (row sums, scalars, arrival counters, balancing norms): one memset launch less for each
+    plan->hsq_clean = true;
+    plan->zero_clean = damp != nullptr;
     if (damp) {
         plan->x_valid = true; plan->x_source = damp->source; plan->x_damping = damp->damping;
         plan->x_seed = damp->seed; plan->x_offset = damp->offset; plan->x_explicit = damp->noise != nullptr;
@@ -1037,7 +1075,8 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
-    HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    P->zero_clean = false;
     P->bal_clean = true;
     if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
         std::vector<uint8_t> all(P->n_tensors, 1);
@@ -1109,7 +1148,8 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
             launch_stage(P, P->g_qupd, st);
             // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
-            DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+            if (P->chain_t()) DISPATCH_T(P, hipLaunchKernelGGL(rsub_t_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+            else DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
             if ((rc = run_nlb(P, 1, nskh, seed, offset, lr, betaL, 1, -1, st))) return rc;
             launch_stage(P, P->g_rq, st);
             launch_stage(P, P->g_rrq, st);
@@ -1241,7 +1281,8 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     }
     const void* const* ng = noise ? (const void* const*)P->d_noise_g : nullptr;
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
-    HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    P->zero_clean = false;
     P->bal_clean = true;
     // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336), unless psgdk_accumulate already wrote exactly this pair
     const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
@@ -1339,7 +1380,8 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
+    if (!P->hsq_clean) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
+    P->hsq_clean = false;
     if ((rc = ensure_P(P, st))) return rc;
     launch_stage(P, P->g_app_a[source], st);
     launch_stage(P, P->g_app_b, st);
@@ -1366,9 +1408,10 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
     for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     int rcp;
-    if ((rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)params, plan->n_tensors, st))) return rcp;
+    void** d_params = nullptr;
+    if ((rcp = plan->ptrs_b.get((const void* const*)params, plan->n_tensors, st, &d_params))) return rcp;
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td, plan->d_tiles_all,
-                                        (void* const*)plan->d_ptr_b, param_dtype, plan->work,
+                                        (void* const*)d_params, param_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp, (void*)nullptr));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
@@ -1457,7 +1500,7 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
     hipStream_t st = (hipStream_t)stream;
     const unsigned b = plan->tile_begin[t], e = plan->tile_begin[t + 1];
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(e - b), dim3(256), 0, st, plan->d_td, plan->d_tiles_all + b,
-                                        (void* const*)plan->d_ptr_a, out_dtype, plan->work,
+                                        (void* const*)nullptr, out_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 1, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, out));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
@@ -1470,9 +1513,10 @@ int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype
     for (int t = 0; t < plan->n_tensors; ++t) if (!outs[t]) return PSGDK_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     int rcp;
-    if ((rcp = upload_ptrs(plan->d_ptr_b, plan->h_ptr_b, (const void* const*)outs, plan->n_tensors, st))) return rcp;
+    void** d_outs = nullptr;
+    if ((rcp = plan->ptrs_b.get((const void* const*)outs, plan->n_tensors, st, &d_outs))) return rcp;
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td, plan->d_tiles_all,
-                                        (void* const*)plan->d_ptr_b, out_dtype, plan->work,
+                                        (void* const*)d_outs, out_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 2, clip, 0.f, 0.f, max_avg_amp, max_elem_amp, (void*)nullptr));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
@@ -1551,6 +1595,50 @@ int psgdk_test_dump_noise(psgdk_plan* plan, uint64_t seed, uint64_t offset, void
     return PSGDK_OK;
 }
 
+int psgdk_test_peaks(float* out4, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!out4 || !scratch || scratch_bytes < (size_t)64 << 20) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int rc = PSGDK_OK;
+    auto timed = [&](auto&& launch, int reps) -> float {          // best of `reps` launches, ms
+        float best = 1e30f;
+        launch();                                                  // warm-up (clocks, code)
+        for (int r = 0; r < reps; ++r) {
+            (void)hipEventRecord(e0, st);
+            launch();
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = PSGDK_ERR_HIP; return best; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        return best;
+    };
+    const int iters = 4000;
+    const unsigned grid = (unsigned)cus * 2;                       // two waves per SIMD
+    const double flops = (double)grid * 4 * iters * 262144.0;     // 2^18 FLOP per wave and round, either shape
+    float* sink = (float*)scratch;
+    const float ms16 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
+    const float ms32 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
+    out4[0] = (float)(flops / (ms16 * 1e-3) / 1e12);
+    out4[1] = (float)(flops / (ms32 * 1e-3) / 1e12);
+    const size_t half = (scratch_bytes / 2) & ~(size_t)255, n = half / 16;
+    const u32x4_t* src = (const u32x4_t*)scratch;
+    u32x4_t* dst = (u32x4_t*)((unsigned char*)scratch + half);
+    const unsigned cgrid = (unsigned)cus * 8;
+    const float msc = timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 0); }, 3);
+    const float msr = timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 1); }, 3);
+    out4[2] = (float)(2.0 * (double)half / (msc * 1e-3) / 1e9);    // read + write
+    out4[3] = (float)((double)half / (msr * 1e-3) / 1e9);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (hipGetLastError() != hipSuccess) rc = PSGDK_ERR_HIP;
+    return rc;
+}
+
 int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
                    int inject_fault, void* stream) {
     if (!plan || (chain != 0 && chain != 1) || (route != 0 && route != 1)) return PSGDK_ERR_INVALID;
@@ -1559,6 +1647,7 @@ int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
+    P->zero_clean = false;
     // what a real update zeroes before the bound: this chain's row sums and arrival counter
     hipLaunchKernelGGL(test_nlb_reset_kernel, dim3(F), dim3(64), 0, st, P->d_dn, P->work, chain);
     int rc = run_nlb(P, chain, nullptr, seed, offset, 0.1f, 0.9f, 1, -1, st, route, inject_fault ? 4096 : 0);

@@ -391,16 +391,30 @@ class KWNS4(torch.optim.Optimizer):
             [self._uniform() for _ in plist]              # keep the gate stream in lock-step with the owning ranks
         work = None
         if self.shard_state:
-            # ONE exchange step: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner is), in place
-            # (RCCL's in-place form: the send buffer IS this rank's segment of the receive buffer) and asynchronous, so that
-            # an update_preconditioner_first=False update below runs while the fabric works
-            mine = b.flat[self.rank * b.seg:(self.rank + 1) * b.seg]
-            in_place = torch.distributed.get_backend() == "nccl"
-            work = torch.distributed.all_gather_into_tensor(b.flat, mine if in_place else mine.clone(), async_op=True)
+            work = self._exchange(b)
         if eng is not None and updateP_last:
+            if work is not None and getattr(eng, "info", None) is not None and eng.info().get("nlb_coop"):
+                # the cooperative norm-bound launch needs all its workgroups resident at once (one per CU); collective kernels that
+                # hold CUs while it starts could run it into its spin limit (one skipped update + a permanent fall-back to the
+                # multi-launch route): let the exchange land first.  The multi-launch route overlaps freely.
+                work.wait()
             eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
                                offset=2 * t + 1, **self._update_draws(b, plist))
         return work
+
+    def _exchange(self, b):
+        """ONE exchange step of a sharded bucket: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner
+        is), asynchronous, so that the next chunk's arithmetic (or an update_preconditioner_first=False update) runs while the
+        fabric works.  The send buffer IS this rank's segment of the receive buffer -- RCCL's in-place form: no staging copy.
+        The aliasing contract of that form is checked on EVERY backend (the gloo tests run this very code): the segment must sit
+        at rank * seg elements inside the gathered buffer, with the buffer's dtype and contiguous.  gloo itself does not accept
+        aliased arguments, so there the (checked) segment is cloned; nothing else differs between the two transports."""
+        flat, seg = b.flat, b.seg
+        mine = flat[self.rank * seg:(self.rank + 1) * seg]
+        assert flat.is_contiguous() and mine.is_contiguous() and flat.numel() == self.world * seg
+        assert mine.data_ptr() == flat.data_ptr() + self.rank * seg * flat.element_size() and mine.dtype == flat.dtype
+        in_place = torch.distributed.get_backend() == "nccl"
+        return torch.distributed.all_gather_into_tensor(flat, mine if in_place else mine.clone(), async_op=True)
 
     def _bucket_finish(self, b, group, plist, work):
         wd, lr = group["weight_decay"], group["lr_params"]

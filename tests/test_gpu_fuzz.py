@@ -56,7 +56,14 @@ def test_tensors_with_9_to_16_dims(shape, geom, max_skew):
     _run_case(7000 + len(shape), shape, max_skew, float("inf"), geom)
 
 
-def _run_case(seed, shape, max_skew, max_size, geom):
+@pytest.mark.parametrize("ndim,geom,steps", [(20, "Q0.5EQ1.5", 2), (20, "QUAD", 2), (26, "Q0.5EQ1.5", 1)])
+def test_tensors_with_20_and_26_dims(ndim, geom, steps):
+    """The reference's limit itself: 26 dims (one einsum letter each, psgd.py:197-198) of extent 2 = 2^26 elements with 26 dense 2 x 2
+    factors (4 <= numel: all dense at max_skew = 1), and 20 dims; PSGDK_MAX_DIMS noise slots per tensor are all in use."""
+    _run_case(7100 + ndim, (2,) * ndim, 1.0, float("inf"), geom, steps=steps)
+
+
+def _run_case(seed, shape, max_skew, max_size, geom, steps=3):
     import psgd_torch_amd as amd
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
     upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
@@ -74,7 +81,7 @@ def _run_case(seed, shape, max_skew, max_size, geom):
     QL, exprs = amd.init_kron(torch.zeros(sq, device=DEV), dQ=geom, **kw)
     QLo, kinds = orc.init_kron(torch.zeros(sq), **(dict(kw, Scale=0.7 ** 2) if p4 else kw))   # psgd.py:186-187
     assert [q.dim() == 2 for q in QL[0]] == [k == "dense" for k in kinds], (shape, kinds)
-    for t in range(3):
+    for t in range(steps):
         G = 0.5 * torch.randn(sq, generator=gen)
         nz = orc.KronNoise.draw(G, kinds, gen)
         nz.balance_u = 0.0 if t == 1 else 1.0                  # exercise the balancing branch once
