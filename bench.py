@@ -6,7 +6,7 @@ of wrapped_as_torch_optimizer_for_ddp.py:98-176 -- momentum EMA, preconditioner 
 Q0.5EQ1.5 geometry, preconditioning, clipping, parameter update -- with bf16 preconditioner state, fp32 parameters and
 synthetic fp32 gradients already resident in HBM.  N > 1: either preconditioner state sharded per parameter across the
 ranks (shard_state=True; the clipped preconditioned gradients are exchanged with one all-gather) or plain replicas --
---parallelism auto (default) times the sharded mode (chunked and single-exchange) and plain replicas in warm-up and keeps the fastest; total work is fixed, so scaling is "strong".
+--parallelism auto (default) times the sharded mode (chunked all-gathers, one all-gather, chunked point-to-point) and plain replicas in warm-up and keeps the fastest; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline     -- for the dominant kernel (the grouped NT MFMA GEMM, both tilings): the algorithmic FLOPs of a step that run in
@@ -335,6 +335,8 @@ def main():
 
     MODES = {"sharded": dict(shard_state=True),                         # 4 chunks: each chunk's all-gather under the next one's arithmetic
              "sharded, one exchange": dict(shard_state=True, shard_chunks=1),
+             "sharded, p2p": dict(shard_state=True, shard_exchange="p2p"),       # every chunk as 2 (N - 1) direct sends / receives
+
              "replicated": dict(shard_state=False), "single": dict(shard_state=False)}
 
     def make(mode_name):
@@ -358,7 +360,7 @@ def main():
         mode = "replicated"
     if dist and args.parallelism == "auto":
         timing, failures = {}, []
-        for name in ("sharded", "sharded, one exchange", "replicated"):
+        for name in ("sharded", "sharded, one exchange", "sharded, p2p", "replicated"):
             # (a mode that raises -- e.g. a collective the installed RCCL / torch refuses -- is dropped from the probe on every rank
             #  alike: argument errors are deterministic; the timed region then runs with what is left)
             try:
@@ -482,7 +484,8 @@ def main():
                                   else "; KWNS4 defaults except whiten_grad=True (momentum 0.9, update probability 1, max_skew 1)"),
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
                    "parallelism": "single GPU" if world == 1 else ({"sharded": f"per-parameter state sharding x{world}, all-gathers of 4 chunks overlapped with the arithmetic",
-                                                                    "sharded, one exchange": f"per-parameter state sharding x{world} + one all-gather per step"}.get(
+                                                                    "sharded, one exchange": f"per-parameter state sharding x{world} + one all-gather per step",
+                                                                    "sharded, p2p": f"per-parameter state sharding x{world}, 4 chunks exchanged by direct point-to-point sends"}.get(
                                                                        mode, f"replicas x{world} (no exchange step)")),
                    "parallelism_probe_ms": ({k: (v * 1e3 if math.isfinite(v) else None) for k, v in timing.items()}
                                             if (dist and args.parallelism == "auto") else None),

@@ -255,7 +255,11 @@ static void layout_arenas(psgdk_plan* P) {
     wo = align256(wo);
     for (auto& F : P->dn) { F.vsq_off = wo; wo += 2 * 4 * 64 * 4; }
     wo = align256(wo);
-    for (auto& F : P->dn) { F.rowss_off = wo; wo += align256((size_t)F.dp * 4); }
+    for (auto& F : P->dn) {
+        F.rowss_off = wo; wo += align256((size_t)F.dp * 4);
+        F.rowss_skh_off = F.rowss_off;
+        if (P->chain_t()) { F.rowss_skh_off = wo; wo += align256((size_t)F.dp * 4); }
+    }
     for (auto& G : P->dd) { G.sum_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
     if (P->geometry == PSGDK_GEOM_EQ)
         for (auto& G : P->dd) { G.sum2_off = wo; wo += align256((size_t)round_up64(G.len) * 4); }
@@ -876,14 +880,16 @@ static int run_balance(psgdk_plan* P, const uint8_t* balance_mask, hipStream_t s
             if (balance_mask[P->gd[gi].tensor])
                 DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
         if (!which.empty()) {
-            HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            BalanceList inl{};
+            if (which.size() <= 15) { inl.n = (int)which.size(); for (size_t i = 0; i < which.size(); ++i) inl.t[i] = which[i]; }
+            else HIPCHK(hipMemcpyAsync(P->d_balance, which.data(), which.size() * sizeof(int), hipMemcpyHostToDevice, st));
             float* balnorm = (float*)(P->work + P->balnorm_off);
             if (!P->bal_clean) HIPCHK(hipMemsetAsync(balnorm, 0, 2 * which.size() * sizeof(float), st));
             P->bal_clean = false;
             const dim3 bg(64, (unsigned)(2 * which.size()));
             for (int phase = 0; phase < 2; ++phase)
                 DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, bg, dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
-                                                 P->d_balance, P->state, balnorm, phase));
+                                                 P->d_balance, inl, P->state, balnorm, phase));
         }
     }
     return PSGDK_OK;
@@ -1148,7 +1154,10 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
             launch_stage(P, P->g_qupd, st);
             // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
-            if (P->chain_t()) DISPATCH_T(P, hipLaunchKernelGGL(rsub_t_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
+            if (P->chain_t()) {
+                const unsigned nb = (unsigned)(P->max_dp / 64);
+                DISPATCH_T(P, hipLaunchKernelGGL(rsub_t_kernel<T>, dim3(nb * (nb + 1) / 2, F), dim3(256), 0, st, P->d_dn, P->work));
+            }
             else DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
             if ((rc = run_nlb(P, 1, nskh, seed, offset, lr, betaL, 1, -1, st))) return rc;
             launch_stage(P, P->g_rq, st);
@@ -1620,18 +1629,21 @@ int psgdk_test_peaks(float* out4, void* scratch, size_t scratch_bytes, void* str
     };
     const int iters = 4000;
     const unsigned grid = (unsigned)cus * 2;                       // two waves per SIMD
-    const double flops = (double)grid * 4 * iters * 262144.0;     // 2^18 FLOP per wave and round, either shape
+    const double flops = (double)grid * 4 * iters * 16 * 16384.0;  // per wave and round: 16 MFMAs of 16 x 16 x 32 (2^18 FLOP); the 32 x 32 x 16 round is 16 MFMAs of twice that
     float* sink = (float*)scratch;
     const float ms16 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
     const float ms32 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
     out4[0] = (float)(flops / (ms16 * 1e-3) / 1e12);
-    out4[1] = (float)(flops / (ms32 * 1e-3) / 1e12);
+    out4[1] = (float)(2.0 * flops / (ms32 * 1e-3) / 1e12);
     const size_t half = (scratch_bytes / 2) & ~(size_t)255, n = half / 16;
     const u32x4_t* src = (const u32x4_t*)scratch;
     u32x4_t* dst = (u32x4_t*)((unsigned char*)scratch + half);
-    const unsigned cgrid = (unsigned)cus * 8;
-    const float msc = timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 0); }, 3);
-    const float msr = timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 1); }, 3);
+    // two launch shapes each (a resident grid with four chunks in flight per thread; one chunk per thread): the better one counts
+    const unsigned cgrid = (unsigned)cus * 8, fgrid = (unsigned)((n + 255) / 256);
+    const float msc = std::min(timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 0); }, 3),
+                               timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(fgrid), dim3(256), 0, st, src, dst, n, 0); }, 3));
+    const float msr = std::min(timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 1); }, 3),
+                               timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(fgrid), dim3(256), 0, st, src, dst, n, 1); }, 3));
     out4[2] = (float)(2.0 * (double)half / (msc * 1e-3) / 1e9);    // read + write
     out4[3] = (float)((double)half / (msr * 1e-3) / 1e9);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -50,6 +50,17 @@ def _unpack(back):
         t.copy_(sh)
 
 
+class _Works:
+    """Several asynchronous requests behind the one-request interface of a collective's work handle."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class _Bucket:
     """The parameters of one param_group that share (param dtype, grad dtype): one engine."""
 
@@ -88,6 +99,7 @@ class KWNS4(torch.optim.Optimizer):
             seed: int = 0,
             shard_state: bool = False,
             shard_chunks: Optional[int] = None,
+            shard_exchange: str = "all_gather",
             engine_factory=None,
     ):
         # the reference's argument checks, verbatim in meaning (..._ddp.py:45-62)
@@ -142,6 +154,11 @@ class KWNS4(torch.optim.Optimizer):
         # sharded mode: the tensors of a bucket are worked off in this many cost-balanced chunks, each with its own exchange
         # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (default 4; 1 = one exchange)
         self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else 4)) if self.shard_state else 1
+        # how a chunk's clipped preconditioned gradients travel: "all_gather" (one collective; RCCL picks the algorithm) or "p2p"
+        # (every rank sends its segment to each peer directly and receives theirs: 2 (N - 1) grouped point-to-point operations, all
+        # seven xGMI links of a GPU busy at once -- a ring all-gather is bound by ONE link).  bench.py --parallelism auto times both.
+        assert shard_exchange in ("all_gather", "p2p")
+        self._shard_exchange = shard_exchange
         self._chunks = {}            # bucket key -> {position of the parameter in its group: chunk index}
         self._seed = int(seed)
         self._gate_gen = torch.Generator().manual_seed(self._seed)      # same stream on every rank
@@ -413,6 +430,13 @@ class KWNS4(torch.optim.Optimizer):
         mine = flat[self.rank * seg:(self.rank + 1) * seg]
         assert flat.is_contiguous() and mine.is_contiguous() and flat.numel() == self.world * seg
         assert mine.data_ptr() == flat.data_ptr() + self.rank * seg * flat.element_size() and mine.dtype == flat.dtype
+        if self._shard_exchange == "p2p":
+            ops = []
+            for r in range(self.world):
+                if r != self.rank:
+                    ops.append(torch.distributed.P2POp(torch.distributed.isend, mine, r))
+                    ops.append(torch.distributed.P2POp(torch.distributed.irecv, flat[r * seg:(r + 1) * seg], r))
+            return _Works(torch.distributed.batch_isend_irecv(ops))
         in_place = torch.distributed.get_backend() == "nccl"
         return torch.distributed.all_gather_into_tensor(flat, mine if in_place else mine.clone(), async_op=True)
 

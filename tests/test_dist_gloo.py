@@ -28,6 +28,7 @@ def _run(params, steps, shard, missing=False, resume=False, **kw):
     from oracle_engine import OracleEngine
     if not shard:
         kw.pop("shard_chunks", None)
+        kw.pop("shard_exchange", None)
 
     def make():
         return psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=shard,
@@ -73,7 +74,8 @@ def _free_port():
                                 dict(preconditioner_update_probability=0.5, momentum=0.5),
                                 dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02),
                                 dict(shard_chunks=1), dict(shard_chunks=3, update_preconditioner_first=False),
-                                dict(missing=True, shard_chunks=2), dict(resume=True), dict(missing=True, resume=True)])
+                                dict(missing=True, shard_chunks=2), dict(resume=True), dict(missing=True, resume=True),
+                                dict(shard_exchange="p2p"), dict(shard_exchange="p2p", shard_chunks=1, update_preconditioner_first=False)])
 def test_sharded_equals_replicated(kw):
     """(missing=True: some parameters have no gradient on some steps -- the reference skips them, ..._ddp.py:113-115; the
     sharded optimizer splits its bucket per parameter, every parameter keeping its owner, and skips their update and decay.)"""
