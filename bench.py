@@ -174,13 +174,27 @@ def bench_lra(args):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
     bytes_alg = (12 + 3) * N * r * 4 + (18 + 3) * N * 4        # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
+    bytes_moved = (12 + 3) * N * r * 4 + 24 * N * 4             # what the kernels move since round 3 (24 vector passes)
+    peaks = None
+    if not args.no_peaks:
+        import ctypes as C
+        from psgd_torch_amd import _lib
+        scratch = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+        scratch.random_(0, 255)
+        pk = (C.c_float * 4)()
+        _lib.check(_lib.lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
+        del scratch
+        peaks = {"hbm_copy_gbs": pk[2], "hbm_read_gbs": pk[3],
+                 "what": "streaming 16-byte copy (read + write) / read of 1 GiB, best of 3, measured in this process after the timed region"}
     out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "fp32", "data": "synthetic",
            "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra",
                       "rank": r},
            "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": None, "algorithmic_gb_per_step": bytes_alg / 1e9}}
+                        "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": None, "algorithmic_gb_per_step": bytes_alg / 1e9,
+                        "moved_gb_per_step": bytes_moved / 1e9, "moved_gbs": bytes_moved / dt / 1e9, "peak_measured": peaks,
+                        "moved_frac_of_measured_read": (bytes_moved / dt / 1e9 / peaks["hbm_read_gbs"]) if peaks else None}}
     print(json.dumps(out), flush=True)
 
 

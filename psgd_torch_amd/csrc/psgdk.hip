@@ -1927,7 +1927,8 @@ int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype) {
     size_t wo = 0;
     L->sm_off = wo; wo += align256((size_t)lra_sm_total(lra_tpr_of_rank(r)) * 4);
     const size_t nb = align256((size_t)N * L->esz);
-    L->v_off = wo; wo += nb; L->h_off = wo; wo += nb; L->qh_off = wo; wo += nb; L->iq_off = wo; wo += nb;
+    L->v_off = L->h_off = 0;      // (v and h are no longer materialised: LraVH)
+    L->qh_off = wo; wo += nb; L->iq_off = wo; wo += nb;
     L->diff_off = wo; wo += nb; L->y_off = wo; wo += nb;
     L->work_bytes = wo;
     *out = L;
@@ -1989,7 +1990,9 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
         T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
         T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
-        hipLaunchKernelGGL(lra_prep_kernel<T>, dim3(gb), dim3(256), 0, st, (const T*)g, (const T*)v_noise, v, h, N, damping, seed, offset);
+        // (no preparation pass: v and h are rebuilt from g where they are used -- LraVH)
+        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset};
+        (void)v; (void)h; (void)gb;
         if (r > 0) {
             hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
             if (shm_s1 > 64u * 1024u)
@@ -1997,23 +2000,23 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
             hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
         }
         if constexpr (TPR == 1)
-            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
         else {      // wider rank classes: the rotation on the fp32 matrix cores (PSGDK_LRA_ROTATE=valu keeps the one-row-per-thread form: A/B)
             static const bool valu = [] { const char* e = std::getenv("PSGDK_LRA_ROTATE"); return e && e[0] == 'v'; }();
             if (valu)
-                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
             else {
                 const int rows_m = LRA_ROWS / TPR;
                 const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
-                hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, (const T*)v, (const T*)h, N, r, sm);
+                hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, vh, N, r, sm);
             }
         }
         hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
-                           (const T*)h, Qh, iq, N, r, sm);
+        hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                           Qh, iq, N, r, sm);
         hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, (const T*)v,
-                           (const T*)h, (const T*)Qh, (const T*)iq, diff, N, r, sm);
+        hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                           (const T*)Qh, (const T*)iq, diff, N, r, sm);
         hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
         hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                            N, r, update_u ? 1 : 0, (const float*)sm);

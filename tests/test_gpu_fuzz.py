@@ -56,6 +56,7 @@ def test_tensors_with_9_to_16_dims(shape, geom, max_skew):
     _run_case(7000 + len(shape), shape, max_skew, float("inf"), geom)
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("ndim,geom,steps", [(20, "Q0.5EQ1.5", 2), (20, "QUAD", 2), (26, "Q0.5EQ1.5", 1)])
 def test_tensors_with_20_and_26_dims(ndim, geom, steps):
     """The reference's limit itself: 26 dims (one einsum letter each, psgd.py:197-198) of extent 2 = 2^26 elements with 26 dense 2 x 2
