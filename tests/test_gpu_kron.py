@@ -212,11 +212,18 @@ def test_kwns4_step_vs_golden(name):
                 assert relerr(params[i].data, gold_p) <= 2e-6 * (t + 1), (name, t, i, "p", relerr(params[i].data, gold_p))
             else:
                 e_hip, e_ref = relerr(params[i].data, p64[i]), relerr(gold_p, p64[i])
-                assert e_hip <= 1.5 * e_ref + 2e-5, (name, t, i, "p", e_hip, e_ref)
+                # (floor: a scalar / few-element parameter sees one bf16 ulp of h -- 0.4 % of lr h -- per step undiluted)
+                assert e_hip <= 1.5 * e_ref + (2e-5 if params[i].numel() > 8 else 6e-5), (name, t, i, "p", e_hip, e_ref)
             st = opt.state[params[i]]
             assert st["step"] == t + 1
             if f"t{t}_ema{i}" in z.files:
-                assert relerr(st["ema"].reshape(-1), z[f"t{t}_ema{i}"].reshape(-1)) <= (1e-6 if dn == "fp32" else 1e-2)
+                got, want = st["ema"].reshape(-1).float().cpu(), torch.from_numpy(z[f"t{t}_ema{i}"].reshape(-1)).float()
+                if dn == "fp32":
+                    # one ulp of the two terms of beta ema + (1 - beta) g, which may cancel (a one-element tensor shows it undiluted)
+                    scale = max(float(want.abs().max()), float(torch.from_numpy(z[f"t{t}_g{i}"]).abs().max()))
+                    assert float((got - want).abs().max()) <= 2.5e-7 * scale, (name, t, i, "ema")
+                else:
+                    assert relerr(got, want) <= 1e-2, (name, t, i, "ema")
             for j in range(len(st["QL"][0])):
                 got_P = P_of([st["QL"][0][j]])[0]
                 gold_P = P_of([torch.from_numpy(z[f"t{t}_p{i}_Q{j}"])])[0]
