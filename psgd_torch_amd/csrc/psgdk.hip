@@ -1118,7 +1118,8 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
                     T* T1 = (T*)(P->work + Fd.t1_off);
                     // chunks of the (a, b) range: enough workgroups to pull the tensor out of HBM at speed (about a thousand), at
                     // least 4096 terms each, and Z s^2 partial sums within the factor's scratch
-                    const int64_t blocks = (int64_t)s_ * ((s_ + 63) / 64), AB = D.numel / s_;
+                    const int64_t blocks = (int64_t)s_ * ((s_ + 63) / 64);
+                    const int64_t AB = D.numel / s_;
                     int64_t Z = std::max<int64_t>(1, std::min<int64_t>(256, 1024 / blocks));
                     Z = std::min<int64_t>(Z, std::max<int64_t>(1, AB / 4096));
                     Z = std::min<int64_t>(Z, std::max<int64_t>(1, (int64_t)PSGDK_GEN_GPART / ((int64_t)s_ * s_)));
