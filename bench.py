@@ -186,13 +186,29 @@ def bench_lra(args):
         del scratch
         peaks = {"hbm_copy_gbs": pk[2], "hbm_read_gbs": pk[3],
                  "what": "streaming 16-byte copy (read + write) / read of 1 GiB, best of 3, measured in this process after the timed region"}
+    traffic = None          # HBM bytes per update + apply from the separate rocprofv3 --pmc passes (profiles/), all LRA launches summed
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_vit-b-lra_latest.json")
+    if os.path.exists(tpath) and r == 10:
+        try:
+            tj = json.load(open(tpath))["kernels"]
+            per_step = {}
+            for k, v in tj.items():
+                if k.startswith("lra_"):
+                    per_step[k] = v["hbm_bytes_per_launch_corrected"] * v["dispatches_traced"]
+            steps_traced = max(1, tj["lra_gram_kernelIf"]["dispatches_traced"]) if "lra_gram_kernelIf" in tj else 3
+            traffic = sum(per_step.values()) / steps_traced
+        except Exception:
+            traffic = None
     out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "fp32", "data": "synthetic",
            "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra",
                       "rank": r},
            "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": None, "algorithmic_gb_per_step": bytes_alg / 1e9,
+                        "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": traffic,
+                        "traffic_source": ("profiles/pmc_traffic_vit-b-lra_latest.json: separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE), "
+                                           "all psgdk_lra_* launches of one update + apply") if traffic else None,
+                        "algorithmic_gb_per_step": bytes_alg / 1e9,
                         "moved_gb_per_step": bytes_moved / 1e9, "moved_gbs": bytes_moved / dt / 1e9, "peak_measured": peaks,
                         "moved_frac_of_measured_read": (bytes_moved / dt / 1e9 / peaks["hbm_read_gbs"]) if peaks else None}}
     print(json.dumps(out), flush=True)
