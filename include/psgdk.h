@@ -130,8 +130,7 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
  *   g_noise[t]            : numel(t) values, the randn_like(G) of psgd.py:403
  *   spd_noise[t*PSGDK_MAX_DIMS+i] : 32 x d_i values, the randn(32,d) of psgd.py:62 for dense factor i of tensor t
  *   skh_noise[t*PSGDK_MAX_DIMS+i] : 32 x d_i values, the randn(32,d) of psgd.py:87
- * A NULL psgdk_noise* selects the built-in counter-based Philox4x32 stream keyed by (seed, offset) (7 rounds for the per-element
- *   damping and start-block noise, 10 for psgdk_fill_normal and the LRA probe). */
+ * A NULL psgdk_noise* selects the built-in counter-based Philox4x32 stream keyed by (seed, offset). */
 typedef struct psgdk_noise {
     const void* const* g_noise;
     const void* const* spd_noise;
