@@ -1,0 +1,81 @@
+"""The gradient reduce-scatter hook for KWNS4(shard_state=True) (psgd_torch_amd/ddp_hook.py) under a real DistributedDataParallel
+model, world 2, gloo, CPU (TEST-ONLY OracleEngine for the compute): after the first iteration every bucket goes through the uneven
+reduce-scatter (all_to_all_single + owner-side sum) instead of an all-reduce, both ranks end with identical parameters, and those equal
+the single-process run on the concatenated batch up to the order of the gradient sums."""
+import os
+import socket
+import sys
+import tempfile
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 10), torch.nn.Tanh(), torch.nn.Linear(10, 4))
+
+
+def _data(step, rank, world):
+    g = torch.Generator().manual_seed(1000 + step)
+    x, y = torch.randn(8 * world, 12, generator=g), torch.randn(8 * world, 4, generator=g)
+    return (x, y) if rank is None else (x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8])
+
+
+def _train(model, opt, steps, rank, world):
+    for t in range(steps):
+        x, y = _data(t, rank, world)
+        opt.zero_grad(set_to_none=True)
+        ((model(x) - y) ** 2).mean().backward()
+        opt.step()
+
+
+KW = dict(preconditioner_dtype=torch.float32, lr_params=1e-2, lr_preconditioner=0.3, weight_decay=0.0)
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import psgd_torch_amd
+        from psgd_torch_amd.ddp_hook import register_sharded_grad_hook
+        from oracle_engine import OracleEngine
+        model = _model(3)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=0.0005)       # several small buckets
+        opt = psgd_torch_amd.KWNS4(ddp.parameters(), shard_state=True, engine_factory=OracleEngine, **KW)
+        st = register_sharded_grad_hook(ddp, opt)
+        _train(ddp, opt, 5, rank, world)
+        torch.save({"params": [p.detach().clone() for p in model.parameters()], "allreduced": st.buckets_allreduced,
+                    "scattered": st.buckets_scattered, "owners": [st.owner_of(p) for p in model.parameters()]},
+                   os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_reduce_scatter_hook_matches_single_process():
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import psgd_torch_amd
+    from oracle_engine import OracleEngine
+    ref = _model(3)
+    opt = psgd_torch_amd.KWNS4(ref.parameters(), engine_factory=OracleEngine, **KW)
+    _train(ref, opt, 5, None, 2)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt"))
+    assert r0["allreduced"] >= 1 and r0["scattered"] >= 4 * r0["allreduced"] > 0, (r0["allreduced"], r0["scattered"])   # first iteration only
+    assert sorted(set(r0["owners"])) == [0, 1] and r0["owners"] == r1["owners"]
+    for a, b, c in zip(r0["params"], r1["params"], ref.parameters()):
+        assert torch.equal(a, b), "ranks diverged"
+        assert torch.allclose(a, c.detach(), rtol=1e-4, atol=1e-6), float((a - c.detach()).abs().max())
