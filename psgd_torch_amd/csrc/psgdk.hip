@@ -74,6 +74,7 @@ struct psgdk_plan {
     // (read at the start of every update call; see nlb_check_error)
     volatile unsigned* h_err = nullptr; unsigned* d_err = nullptr;
     int64_t nlb_fallbacks = 0;        // how often a timeout moved this plan to the multi-launch route (0 or 1)
+    bool nlb_narrow = false;         // PSGDK_NLB_WIDE=0: the 4-byte publish stores of rounds 1-2 (A/B)
     bool nlb_unfused = false;        // PSGDK_NLB_FUSED=0 at plan creation: keep the multi-launch route (tests compare the two)
     bool p_valid = false;
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
@@ -994,9 +995,12 @@ static int nlb_plan_coop(psgdk_plan* P) {
         P->h_err = (volatile unsigned*)h; P->d_err = (unsigned*)d;
     }
     P->n_nlb_jobs = (unsigned)jobs.size();
-    P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16));
-    const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
-    HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    // the subspace block (32 rows of the widest factor + 16 bytes each) + eight wave-private publish stages of 32 x (32 T + 16 bytes)
+    P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16) + 8 * 32 * (32 * P->esz + 16));
+    { const char* e = getenv("PSGDK_NLB_WIDE"); P->nlb_narrow = e && e[0] == '0'; }
+    for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
+                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, false>, (const void*)nlb_coop_kernel<float, 2, 24, false>})
+        HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
 }
@@ -1004,7 +1008,8 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
                    int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
-        const void* k = P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>;
+        const void* k = P->nlb_narrow ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, false> : (const void*)nlb_coop_kernel<float, 2, 24, false>)
+                                      : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
         void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
