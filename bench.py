@@ -433,6 +433,21 @@ def main():
     sample = 4 if args.steps >= 8 else 1
     prof_steps = 0
 
+    # the collector's work inside the timed region is reported next to the host time (config.gc_in_timed_region): a full
+    # collection of torch's heap costs ~35 ms, which is 20 steps of this workload
+    import gc
+    gc_ms = [0.0]
+    gc_t = [0.0]
+
+    def gc_watch(phase, info):
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_ms[0] += (time.perf_counter() - gc_t[0]) * 1e3
+    gc.collect()
+    gc_before = [g["collections"] for g in gc.get_stats()]
+    gc.callbacks.append(gc_watch)
+
     fence = sync_all
     fence()
     t0 = time.perf_counter()
@@ -446,6 +461,9 @@ def main():
     host_dt = time.perf_counter() - t0          # host enqueue time (no sync inside): shows whether the host keeps ahead
     fence()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_watch)
+    gc_in_timed = {"collections_by_generation": [g["collections"] - b for g, b in zip(gc.get_stats(), gc_before)],
+                   "ms_per_step": gc_ms[0] / args.steps}
     gemm_ms, gemm_launches = 0.0, 0
     for e in engines:
         ms, n = e.profile_read(reset=True)
@@ -520,7 +538,7 @@ def main():
                    "parallelism_probe_ms": ({k: (v * 1e3 if math.isfinite(v) else None) for k, v in timing.items()}
                                             if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-                   "apply_only_ms_per_step": apply_only_ms,
+                   "gc_in_timed_region": gc_in_timed, "apply_only_ms_per_step": apply_only_ms,
                    "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products",
                    "norm_bound_timeouts": nlb_fallbacks, "state_finite_after_timed_region": True},
     }

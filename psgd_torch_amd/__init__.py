@@ -18,7 +18,15 @@ from .kwns4 import KWNS4  # noqa: F401
 from .engine import KronEngine  # noqa: F401
 from .kron_whiten import KronWhiten  # noqa: F401
 from .lra import LRAWhiten, precond_grad_lra, update_precond_lra_whiten  # noqa: F401
-from .ddp_hook import register_sharded_grad_hook  # noqa: F401
+
+
+def __getattr__(name):
+    # the DDP comm hook is resolved on first use: single-GPU users never import the DistributedDataParallel side
+    if name == "register_sharded_grad_hook":
+        from .ddp_hook import register_sharded_grad_hook
+        return register_sharded_grad_hook
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
 
 __all__ = ["KWNS4", "KronWhiten", "KronEngine", "init_kron", "update_precond_kron_whiten_q0p5eq1p5", "update_precond_kron_whiten_eq",
            "update_precond_kron_whiten_qeq", "update_precond_kron_whiten_quad", "update_precond_kron_whiten_qep", "update_precond_kron_whiten_quad4p", "update_precond_kron_whiten_pro4p",
