@@ -523,9 +523,15 @@ class KWNS4(torch.optim.Optimizer):
         Buckets are built lazily, so this may be called right after construction; the arenas are filled when a bucket is first
         used.  Buckets that had been split into per-parameter engines (parameters without gradients on some steps) come back
         split."""
+        # every check first: a checkpoint that does not fit leaves the optimizer untouched
         assert sd.get("psgdk_version") == 2, "not a psgd_torch_amd.KWNS4 state dict (version 2)"
+        if sd.get("dQ", "Q0.5EQ1.5") != self.dQ:
+            raise ValueError(f"checkpoint was taken with dQ={sd.get('dQ')!r}, this optimizer uses dQ={self.dQ!r}")
+        assert sd.get("shard_chunks", 1) == self._shard_chunks, "checkpoint was taken with another shard_chunks"
+        assert len(sd["param_groups"]) == len(self.param_groups), "checkpoint does not match this optimizer"
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             assert len(saved["params"]) == len(g["params"]), "checkpoint does not match this optimizer"
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})
         self._global_step = sd["global_step"]
         self._seed = sd["seed"]
@@ -533,7 +539,6 @@ class KWNS4(torch.optim.Optimizer):
 
         def _dt(s):
             return None if s == "None" else getattr(torch, s.split(".")[-1])
-        assert sd.get("shard_chunks", 1) == self._shard_chunks, "checkpoint was taken with another shard_chunks"
 
         def _key(parts):
             gi, pdt, gdt, dev = parts[:4]
@@ -555,8 +560,6 @@ class KWNS4(torch.optim.Optimizer):
             return "|".join(f)
         self._pending_restore = {_norm(k): v for k, v in sd["buckets"].items()}
         self._restore_warned = False
-        if sd.get("dQ", "Q0.5EQ1.5") != self.dQ:
-            raise ValueError(f"checkpoint was taken with dQ={sd.get('dQ')!r}, this optimizer uses dQ={self.dQ!r}")
         for key, b in self._buckets.items():
             ks = self._key_str(key)
             if ks in self._pending_restore:
