@@ -36,14 +36,7 @@ def _numel(shape) -> int:
     return n
 
 
-def _check_tensors(what: str, tensors: Sequence[torch.Tensor], numels: Sequence[int], device) -> torch.dtype:
-    """The library takes raw device pointers and walks them in logical-contiguous order with ONE element type per call: a
-    strided view (channels_last weight, transposed / tied view), a tensor on another device or a mixed-dtype list would be
-    read and written wrongly without any error -- the reference's `p.subtract_(h.view_as(p))` is stride-safe
-    (wrapped_as_torch_optimizer_for_ddp.py:157), raw pointers are not.  Refuse instead of corrupting."""
-    if len(tensors) != len(numels):
-        raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}: expected {len(numels)} tensors, got {len(tensors)}")
-    dt = tensors[0].dtype if len(tensors) else torch.float32
+def _explain_bad_tensor(what, tensors, numels, device, dt):
     for k, (t, n) in enumerate(zip(tensors, numels)):
         if not isinstance(t, torch.Tensor):
             raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] is not a tensor")
@@ -58,6 +51,23 @@ def _check_tensors(what: str, tensors: Sequence[torch.Tensor], numels: Sequence[
             raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}[{k}] is not contiguous (strides {tuple(t.stride())} for shape "
                                                     f"{tuple(t.shape)}): the HIP engine addresses tensors by raw pointer in "
                                                     "logical-contiguous order")
+    raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}: a tensor failed validation")      # (not reached)
+
+
+def _check_tensors(what: str, tensors: Sequence[torch.Tensor], numels: Sequence[int], device) -> torch.dtype:
+    """The library takes raw device pointers and walks them in logical-contiguous order with ONE element type per call: a
+    strided view (channels_last weight, transposed / tied view), a tensor on another device or a mixed-dtype list would be
+    read and written wrongly without any error -- the reference's `p.subtract_(h.view_as(p))` is stride-safe
+    (wrapped_as_torch_optimizer_for_ddp.py:157), raw pointers are not.  Refuse instead of corrupting."""
+    if len(tensors) != len(numels):
+        raise L.PsgdkError(L.PSGDK_ERR_INVALID, f"{what}: expected {len(numels)} tensors, got {len(tensors)}")
+    dt = tensors[0].dtype if len(tensors) else torch.float32
+    Tensor = torch.Tensor
+    for t, n in zip(tensors, numels):
+        # one combined test per tensor on the way every step takes (this runs for every gradient and parameter of every call);
+        # what exactly is wrong is worked out only when something is
+        if not (isinstance(t, Tensor) and t.dtype is dt and t.numel() == n and t.is_contiguous() and t.device == device):
+            _explain_bad_tensor(what, tensors, numels, device, dt)
     L.dtype_code(dt)       # bf16 / fp32 only
     return dt
 

@@ -169,6 +169,7 @@ class KWNS4(torch.optim.Optimizer):
         self._split = set()          # bucket keys that fell back to one engine per parameter
         self._split_pd = {}
         self._split_owner = {}       # sharded mode: owner rank of every split-off parameter (kept from the batched bucket)
+        self._pos_cache = {}
 
     # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
     # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
@@ -185,14 +186,32 @@ class KWNS4(torch.optim.Optimizer):
     def _uniform(self) -> float:
         return float(torch.rand([], generator=self._gate_gen))
 
+    def _uniforms(self, n: int) -> List[float]:
+        """n successive gate draws.  One generator call instead of n: `torch.rand(n, generator=g)` consumes the CPU generator
+        exactly like n calls of `torch.rand([], generator=g)` (same values, same final state -- tests/test_missing_grads.py checks
+        it), and 148 scalar draws were 0.4 ms of the 0.6 ms of host time per GPT-2-small step.  A replaced `_uniform` (the tests
+        that replay the reference's recorded draws set it on the instance) is honoured draw by draw."""
+        if "_uniform" in self.__dict__ or type(self)._uniform is not KWNS4._uniform:
+            return [self._uniform() for _ in range(n)]
+        return torch.rand(n, generator=self._gate_gen).tolist()
+
     def _update_draws(self, b, plist):
         """The host-side draws of one batched update call: the per-tensor 1% balancing gates of psgd.py:418 (drawn for
         ALL tensors on every rank so that the gate stream stays identical across ranks); device noise is Philox unless
         a test installed `_replay` to feed the reference's recorded draws."""
         if self._replay is not None:
             return self._replay(b, plist)
-        u = [self._uniform() for _ in plist]
+        u = self._uniforms(len(plist))
         return dict(noise=None, balance_mask=[u[i] < 0.01 for i in b.owned])
+
+    def _pos(self, gi: int, group) -> Dict[int, int]:
+        """id(parameter) -> its position in the group (the Philox stream id, the chunk and split keys): built once per group and
+        rebuilt when the group's parameter list changes (add_param_group, a list edited in place)."""
+        c = self._pos_cache.get(gi)
+        params = group["params"]
+        if c is None or c[0] is not params or c[1] != len(params):
+            c = self._pos_cache[gi] = (params, len(params), {id(p): k for k, p in enumerate(params)})
+        return c[2]
 
     # --------------------------------------------------------------------------------------------------------------
     def _buckets_for(self, gi: int, group, plist: List[torch.Tensor]):
@@ -206,7 +225,7 @@ class KWNS4(torch.optim.Optimizer):
         key = (gi, p0.dtype, g0.dtype, p0.device)
         if self._shard_chunks <= 1:
             return self._buckets_for_key(gi, group, plist, key)
-        pos = {id(p): k for k, p in enumerate(group["params"])}
+        pos = self._pos(gi, group)
         ch = self._chunks.get(key)           # {position in the group: chunk}; part of the checkpoint
         if ch is None:
             shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]
@@ -221,7 +240,7 @@ class KWNS4(torch.optim.Optimizer):
         return out
 
     def _buckets_for_key(self, gi: int, group, plist: List[torch.Tensor], key):
-        pos = {id(p): k for k, p in enumerate(group["params"])}
+        pos = self._pos(gi, group)
         if key in self._split:
             out = []
             for p in plist:
@@ -242,7 +261,7 @@ class KWNS4(torch.optim.Optimizer):
                     return None if x in (None, "None") else getattr(torch, x.split(".")[-1])
                 b = self._bucket_for(gi, group, had, key=key, shapes=[tuple(self._data_of(p).squeeze().shape) for p in had],
                                      pd=_dt(saved.get("pd")))
-        if b is not None and [id(p) for p in b.params] != [id(p) for p in plist]:
+        if b is not None and b.param_ids != tuple(map(id, plist)):
             self._split_bucket(gi, group, key, b, pos)
             return self._buckets_for_key(gi, group, plist, key)
         return [(self._bucket_for(gi, group, plist, key=key), plist)]
@@ -281,9 +300,10 @@ class KWNS4(torch.optim.Optimizer):
             return b
         b = _Bucket()
         b.params = list(plist)
+        b.param_ids = tuple(map(id, plist))
         # Philox stream ids = position of the parameter in its group: the same on every rank, whatever subset of the group
         # a rank works on (sharded ownership; DTensor ranks whose local shard of some parameter is empty)
-        pos = {id(p): k for k, p in enumerate(group["params"])}
+        pos = self._pos(gi, group)
         if pd is None:
             pd = group["preconditioner_dtype"] or self._grad_of(plist[0]).dtype
         if shapes is None:
@@ -405,7 +425,7 @@ class KWNS4(torch.optim.Optimizer):
                 # all owned tensors' clipped h straight into this rank's segment of the exchange buffer: one launch
                 eng.export_precond_grad([b.h_views[i] for i in b.owned], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
         elif updateP_first or updateP_last:
-            [self._uniform() for _ in plist]              # keep the gate stream in lock-step with the owning ranks
+            self._uniforms(len(plist))                    # keep the gate stream in lock-step with the owning ranks
         work = None
         if self.shard_state:
             work = self._exchange(b)

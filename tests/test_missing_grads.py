@@ -224,3 +224,22 @@ def test_checkpoint_does_not_depend_on_the_device_index():
         assert torch.equal(p.data, q.data)
         for a, b in zip(opt.state[p]["QL"][0], opt2.state[q]["QL"][0]):
             assert torch.equal(a, b)
+
+
+def test_batched_gate_draws_are_the_scalar_stream():
+    """KWNS4._uniforms(n) draws the n per-tensor balancing gates of one update call with ONE generator call; it must be the stream
+    n scalar draws give (values and final generator state), so that checkpoints, ranks and the recorded-draw tests of earlier rounds
+    see the same gates -- and a replaced `_uniform` (how the golden tests replay the reference's draws) must still be honoured."""
+    import psgd_torch_amd
+    p = [torch.nn.Parameter(torch.zeros(3, 2))]
+    for n in (1, 5, 16, 17, 148, 292):
+        a = psgd_torch_amd.KWNS4(p, seed=7, engine_factory=OracleEngine)
+        b = psgd_torch_amd.KWNS4(p, seed=7, engine_factory=OracleEngine)
+        one_by_one = [a._uniform() for _ in range(n)]
+        assert b._uniforms(n) == one_by_one
+        assert torch.equal(a._gate_gen.get_state(), b._gate_gen.get_state())
+        assert a._uniform() == b._uniform()
+    c = psgd_torch_amd.KWNS4(p, seed=7, engine_factory=OracleEngine)
+    seq = iter([0.25, 0.5, 0.75])
+    c._uniform = lambda: next(seq)
+    assert c._uniforms(3) == [0.25, 0.5, 0.75]
