@@ -103,6 +103,7 @@ TEST_SIGNATURES = {
     "psgdk_test_dump_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "psgdk_test_peaks": (C.c_int, [C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "psgdk_test_nlb_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "psgdk_test_nlb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -70,6 +70,7 @@ struct psgdk_plan {
     int max_dp = 0;
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
+    unsigned long long* d_nlb_ts = nullptr;   // psgdk_test_nlb_stamps: NLB_TS_SLOTS words per workgroup (its address sits after the job table)
     // error word of the cooperative kernels: host-mapped pinned memory, so that the host can look at it WITHOUT synchronising
     // (read at the start of every update call; see nlb_check_error)
     volatile unsigned* h_err = nullptr; unsigned* d_err = nullptr;
@@ -115,7 +116,7 @@ struct psgdk_plan {
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
-        fr(d_uinv); fr(d_nlb_jobs);
+        fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_ts);
         if (h_err) (void)hipHostFree((void*)h_err);
     }
 };
@@ -985,6 +986,16 @@ static int nlb_plan_coop(psgdk_plan* P) {
     std::vector<NlbJob> jobs(8 * len, NlbJob{-1, 0, 0, 0});
     for (size_t x = 0; x < 8; ++x)
         for (size_t k = 0; k < xcd[x].size(); ++k) jobs[k * 8 + x] = xcd[x][k];
+    // one entry more than the grid reads: the address of the stamp buffer of the instrumented instantiation (TS; test hook only)
+    const size_t n_jobs = jobs.size();
+    if (P->d_nlb_ts) { (void)hipFree(P->d_nlb_ts); P->d_nlb_ts = nullptr; }
+    HIPCHK(hipMalloc((void**)&P->d_nlb_ts, n_jobs * NLB_TS_SLOTS * sizeof(unsigned long long)));
+    {
+        NlbJob tail{0, 0, 0, 0};
+        static_assert(sizeof(NlbJob) >= sizeof(void*), "the stamp buffer's address must fit a job entry");
+        std::memcpy(&tail, &P->d_nlb_ts, sizeof(void*));
+        jobs.push_back(tail);
+    }
     int rc = upload(&P->d_nlb_jobs, jobs);
     if (rc) return rc;
     if (!P->h_err) {
@@ -994,21 +1005,23 @@ static int nlb_plan_coop(psgdk_plan* P) {
         HIPCHK(hipHostGetDevicePointer(&d, h, 0));
         P->h_err = (volatile unsigned*)h; P->d_err = (unsigned*)d;
     }
-    P->n_nlb_jobs = (unsigned)jobs.size();
+    P->n_nlb_jobs = (unsigned)n_jobs;
     // the subspace block (32 rows of the widest factor + 16 bytes each) + eight wave-private publish stages of 32 x (32 T + 16 bytes)
     P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16) + 8 * 32 * (32 * P->esz + 16));
     { const char* e = getenv("PSGDK_NLB_WIDE"); P->nlb_narrow = e && e[0] == '0'; }
     for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
-                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, false>, (const void*)nlb_coop_kernel<float, 2, 24, false>})
+                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, false>, (const void*)nlb_coop_kernel<float, 2, 24, false>,
+                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, true, true>, (const void*)nlb_coop_kernel<float, 2, 24, true, true>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
 }
 static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t seed, uint64_t offset, float lr, float betaL,
-                   int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0) {
+                   int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0, bool stamps = false) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
-        const void* k = P->nlb_narrow ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, false> : (const void*)nlb_coop_kernel<float, 2, 24, false>)
+        const void* k = stamps ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true, true> : (const void*)nlb_coop_kernel<float, 2, 24, true, true>)
+                      : P->nlb_narrow ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, false> : (const void*)nlb_coop_kernel<float, 2, 24, false>)
                                       : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
@@ -1686,6 +1699,27 @@ int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64
     DISPATCH_T(P, hipLaunchKernelGGL(test_nlb_collect_kernel<T>, dim3(F), dim3(256), 0, st, P->d_dn, P->work, chain, P->max_dp, out_vsq,
                                      (T*)out_v));
     HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_test_nlb_stamps(psgdk_plan* plan, int chain, uint64_t seed, uint64_t offset, unsigned long long* out, int max_blocks,
+                          int* n_blocks, void* stream) {
+    if (!plan || (chain != 0 && chain != 1) || !out || !n_blocks || max_blocks <= 0) return PSGDK_ERR_INVALID;
+    if (!plan->state || plan->dn.empty() || !plan->d_nlb_jobs || !plan->d_nlb_ts) return PSGDK_ERR_STATE;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned F = (unsigned)P->dn.size();
+    const size_t words = (size_t)P->n_nlb_jobs * NLB_TS_SLOTS;
+    P->zero_clean = false;
+    HIPCHK(hipMemsetAsync(P->d_nlb_ts, 0, words * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(test_nlb_reset_kernel, dim3(F), dim3(64), 0, st, P->d_dn, P->work, chain);
+    int rc = run_nlb(P, chain, nullptr, seed, offset, 0.1f, 0.9f, 1, -1, st, 1, 0, true);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    const int nb = (int)std::min<size_t>((size_t)max_blocks, (size_t)P->n_nlb_jobs);
+    HIPCHK(hipMemcpyAsync(out, P->d_nlb_ts, (size_t)nb * NLB_TS_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *n_blocks = nb;
     return PSGDK_OK;
 }
 

@@ -75,6 +75,14 @@ def main():
     changed = [k for k in base if k in fp and fp[k]["code"] != base[k]["code"]]
     gone = [k for k in base if k not in fp]
     new = [k for k in fp if k not in base]
+    # a kernel whose template signature grew a defaulted parameter has a new mangled name and the same code: pair them by hash
+    renamed = []
+    for k in list(gone):
+        m = [n for n in new if fp[n]["code"] == base[k]["code"] and n.split("I")[0] == k.split("I")[0]]
+        if m:
+            renamed.append((k, m[0]))
+            gone.remove(k)
+            new.remove(m[0])
     dem = subprocess.run(["c++filt"] + changed + gone + new, capture_output=True, text=True).stdout.splitlines() if (changed or gone or new) else []
     it = iter(dem)
     for tag, lst in (("CHANGED", changed), ("GONE", gone), ("new", new)):
@@ -82,7 +90,11 @@ def main():
             d = next(it)
             extra = f"  insns {base[k]['insns']} -> {fp[k]['insns']}" if tag == "CHANGED" else ""
             print(f"{tag:8s} {re.sub(r'[(].*', '', d)[:110]}{extra}")
-    print(f"{len(base) - len(changed) - len(gone)} of {len(base)} functions unchanged, {len(changed)} changed, {len(gone)} gone, {len(new)} new")
+    for k, n in renamed:
+        d = subprocess.run(["c++filt", k, n], capture_output=True, text=True).stdout.splitlines()
+        print(f"renamed  {re.sub(r'[(].*', '', d[0])[:70]} -> {re.sub(r'[(].*', '', d[1])[:70]} (same code)")
+    print(f"{len(base) - len(changed) - len(gone)} of {len(base)} functions unchanged ({len(renamed)} of them under a new name), "
+          f"{len(changed)} changed, {len(gone)} gone, {len(new)} new")
     return 1 if changed or gone else 0
 
 
