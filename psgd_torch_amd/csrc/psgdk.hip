@@ -27,6 +27,7 @@ struct Stage {                       // one grouped GEMM launch
     bool lock = false;               // tests / experiments: the lock-step main loop of the 256x256 tiling
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
+    bool ksplit = false;             // small plans (PSGDK_GEMM_KSPLIT): 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -134,8 +135,8 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
-    tb.bm = s.big ? GEMM_BIG_BM : GEMM_BM;
-    tb.bn = s.big ? GEMM_BIG_BN : GEMM_BN;
+    tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
+    tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
@@ -149,6 +150,14 @@ int finish_stage(Stage& s) {
 static bool big_lockstep() {
     static const int v = [] { const char* e = getenv("PSGDK_GEMM_BIG"); return (e && e[0] == 'l') ? 1 : 0; }();
     return v != 0;
+}
+// PSGDK_GEMM_KSPLIT=n (experiment, off when unset): a stage whose problems make at most n tiles of 128 x 128 ("1" = 64) runs on 64 x 64
+// tiles with the K loop split over the workgroup's waves (gemm_nt_ks_kernel)
+static int64_t ksplit_max_tiles() {   // (read at every bind)
+    const char* e = getenv("PSGDK_GEMM_KSPLIT");
+    if (!e || !e[0] || e[0] == '0') return 0;
+    const int64_t v = atoll(e);
+    return v <= 1 ? 64 : v;
 }
 static int64_t big_min_tiles() {      // (read at every bind: the tests force the big tiling onto small plans with it)
     const char* e = getenv("PSGDK_BIG_MIN_TILES");
@@ -174,6 +183,7 @@ void launch_stage_t(const Stage& s, hipStream_t st) {
     if (s.big && (s.lock || big_lockstep())) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
     else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
                                        s.d_probs, s.d_tiles, (int)s.n_tiles);
+    else if (s.ksplit) hipLaunchKernelGGL(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
 }
@@ -834,6 +844,21 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
         // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
+        // small plans (experiment): few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
+        s->ksplit = false;
+        if (const int64_t kmax = ksplit_max_tiles(); kmax > 0 && !s->big && !s->ext && !s->probs.empty()) {
+            const int bk = P->dtype == PSGDK_BF16 ? 64 : 32;
+            int64_t n128 = 0;
+            bool ok = true;
+            for (const GemmProblem& g : s->probs) {
+                const int64_t tm = (g.M + GEMM_BM - 1) / GEMM_BM, tn = (g.N + GEMM_BN - 1) / GEMM_BN;
+                const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+                n128 += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+                ok = ok && g.M % 64 == 0 && g.N % 64 == 0 && g.K % bk == 0 && g.K >= bk &&
+                     (!(g.flags & GF_SPLITK) || g.kchunk % bk == 0);
+            }
+            s->ksplit = ok && n128 <= kmax;
+        }
     }
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;

@@ -1,0 +1,33 @@
+#!/bin/bash
+# First GPU call of the next round: the two experiments that were written after round 3's GPU budget was spent (nothing in the default path
+# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~3 minutes of box time.
+#   1. tools/nlb_stamps.py -- where the 67 us of a cooperative norm bound go (instrumented instantiation, psgdk_test_nlb_stamps)
+#   2. PSGDK_GEMM_KSPLIT=1 -- 64 x 64 tiles with the K loop split over the waves for stages of few tiles (gemm_nt_ks_kernel): parity on every
+#      small-plan test, then LeNet5's step with and without it, same box
+OUT=gpurun_out/r04_prepared
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=$(pwd)
+# (each experiment under its own timeout: blind code)
+timeout 60 python tools/nlb_stamps.py --width 768 --factors 62 --dtype bf16 > $OUT/nlb_stamps_bf16_768.txt 2>&1; echo "exit $?" >> $OUT/nlb_stamps_bf16_768.txt
+timeout 60 python tools/nlb_stamps.py --width 320 --factors 24 --dtype fp32 > $OUT/nlb_stamps_fp32_320.txt 2>&1; echo "exit $?" >> $OUT/nlb_stamps_fp32_320.txt
+timeout 60 python tools/nlb_stamps.py --width 128 --factors 5 --dtype fp32 > $OUT/nlb_stamps_fp32_128_solo.txt 2>&1; echo "exit $?" >> $OUT/nlb_stamps_fp32_128_solo.txt
+# K-split tiles: the GEMM kernel test itself does not go through plan_bind; everything below does
+PSGDK_GEMM_KSPLIT=1 timeout 300 python -m pytest tests/test_gpu_kron.py tests/test_gpu_eq.py -m gpu -q -p no:cacheprovider -x \
+    -k "functional_seam or kwns4_step or kronwhiten or known_answer or degenerate or eq" > $OUT/pytest_ksplit.log 2>&1; echo "exit $?" >> $OUT/pytest_ksplit.log
+PSGDK_GEMM_KSPLIT=1 timeout 200 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider -x > $OUT/pytest_ksplit_fuzz.log 2>&1; echo "exit $?" >> $OUT/pytest_ksplit_fuzz.log
+for v in 0 1; do
+  PSGDK_GEMM_KSPLIT=$v python bench.py --config lenet5 --steps 200 --warmup 20 --no-cpu-baseline --no-apply-only --no-peaks > $OUT/bench_lenet5_ksplit$v.json 2>> $OUT/bench.err
+  ( cd /tmp && PSGDK_GEMM_KSPLIT=$v rocprofv3 --kernel-trace --stats -d /tmp/p_k$v -- python $R/bench.py --config lenet5 --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > /dev/null 2>> $R/$OUT/rocprof.err
+    db=$(find /tmp/p_k$v -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/lenet5_step_sequence_ksplit$v.md )
+done
+tail -25 $OUT/nlb_stamps_bf16_768.txt; tail -3 $OUT/pytest_ksplit.log; tail -3 $OUT/pytest_ksplit_fuzz.log
+python - <<'EOF'
+import json
+for v in (0, 1):
+    try:
+        d = json.loads(open(f"gpurun_out/r04_prepared/bench_lenet5_ksplit{v}.json").read().strip().splitlines()[-1])
+        print("lenet5 ksplit", v, round(d["ms_per_step"], 4), "ms/step")
+    except Exception as e:
+        print("lenet5 ksplit", v, "failed:", e)
+EOF
