@@ -1,6 +1,6 @@
 #!/bin/bash
-# First GPU call of the next round: the two experiments that were written after round 3's GPU budget was spent (nothing in the default path
-# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~3 minutes of box time.
+# First GPU call of the next round: the three experiments that were written after round 3's GPU budget was spent (nothing in the default path
+# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~5 minutes of box time.
 #   1. tools/nlb_stamps.py -- where the 67 us of a cooperative norm bound go (instrumented instantiation, psgdk_test_nlb_stamps)
 #   2. PSGDK_GEMM_KSPLIT=1 -- 64 x 64 tiles with the K loop split over the waves for stages of few tiles (gemm_nt_ks_kernel): parity on every
 #      small-plan test, then LeNet5's step with and without it, same box
@@ -21,6 +21,15 @@ for v in 0 1; do
   ( cd /tmp && PSGDK_GEMM_KSPLIT=$v rocprofv3 --kernel-trace --stats -d /tmp/p_k$v -- python $R/bench.py --config lenet5 --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > /dev/null 2>> $R/$OUT/rocprof.err
     db=$(find /tmp/p_k$v -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/lenet5_step_sequence_ksplit$v.md )
 done
+# 3. PSGDK_ACC_EARLY_EMA=1 -- the momentum pass with the EMA loads issued before the noise chain (accumulate_kernel<T, true>): parity, then
+#    the GPT-2-small step with and without it on this box (dispatch sequence: accumulate_kernel's duration)
+PSGDK_ACC_EARLY_EMA=1 timeout 300 python -m pytest tests/test_gpu_kron.py tests/test_gpu_production_path.py -m gpu -q -p no:cacheprovider -x \
+    -k "kwns4_step or kronwhiten or functional_seam or fp32 or small_full_plan and True" > $OUT/pytest_early_ema.log 2>&1; echo "exit $?" >> $OUT/pytest_early_ema.log
+for v in 0 1; do
+  ( cd /tmp && PSGDK_ACC_EARLY_EMA=$v rocprofv3 --kernel-trace --stats -d /tmp/p_e$v -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > $R/$OUT/bench_early_ema$v.json 2>> $R/$OUT/rocprof.err
+    db=$(find /tmp/p_e$v -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/step_sequence_early_ema$v.md )
+done
+tail -3 $OUT/pytest_early_ema.log; for v in 0 1; do echo early_ema=$v; grep accumulate $OUT/step_sequence_early_ema$v.md; tail -1 $OUT/step_sequence_early_ema$v.md; done
 tail -25 $OUT/nlb_stamps_bf16_768.txt; tail -3 $OUT/pytest_ksplit.log; tail -3 $OUT/pytest_ksplit_fuzz.log
 python - <<'EOF'
 import json
