@@ -960,19 +960,22 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
         }
         do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
     }
-    static const bool early_ema = [] { const char* e = getenv("PSGDK_ACC_EARLY_EMA"); return e && e[0] == '1'; }();      // experiment
+    static const int early_ema = [] { const char* e = getenv("PSGDK_ACC_EARLY_EMA"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();   // experiment
 #define PSGDK_ACC_ARGS dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,                                                      \
                        plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,                              \
                        plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,              \
                        do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0,                     \
                        (unsigned long long)plan->hsumsq_off, (unsigned)plan->n_tensors,                                           \
                        (unsigned long long)plan->zero_off, (unsigned long long)(damp ? plan->zero_bytes : 0)
-    if (early_ema) {
-        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, true>), PSGDK_ACC_ARGS);
-        else hipLaunchKernelGGL((accumulate_kernel<float, true>), PSGDK_ACC_ARGS);
+    if (early_ema == 2) {
+        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 2>), PSGDK_ACC_ARGS);
+        else hipLaunchKernelGGL((accumulate_kernel<float, 2>), PSGDK_ACC_ARGS);
+    } else if (early_ema == 1) {
+        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 1>), PSGDK_ACC_ARGS);
+        else hipLaunchKernelGGL((accumulate_kernel<float, 1>), PSGDK_ACC_ARGS);
     } else {
-        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, false>), PSGDK_ACC_ARGS);
-        else hipLaunchKernelGGL((accumulate_kernel<float, false>), PSGDK_ACC_ARGS);
+        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 0>), PSGDK_ACC_ARGS);
+        else hipLaunchKernelGGL((accumulate_kernel<float, 0>), PSGDK_ACC_ARGS);
     }
 #undef PSGDK_ACC_ARGS
     HIPCHK(hipGetLastError());

@@ -23,13 +23,16 @@ for v in 0 1; do
 done
 # 3. PSGDK_ACC_EARLY_EMA=1 -- the momentum pass with the EMA loads issued before the noise chain (accumulate_kernel<T, true>): parity, then
 #    the GPT-2-small step with and without it on this box (dispatch sequence: accumulate_kernel's duration)
-PSGDK_ACC_EARLY_EMA=1 timeout 300 python -m pytest tests/test_gpu_kron.py tests/test_gpu_production_path.py -m gpu -q -p no:cacheprovider -x \
-    -k "kwns4_step or kronwhiten or functional_seam or fp32 or small_full_plan and True" > $OUT/pytest_early_ema.log 2>&1; echo "exit $?" >> $OUT/pytest_early_ema.log
-for v in 0 1; do
+#    (=2: plus the straight-line path for interior tiles -- gradient, parameter and EMA groups requested back to back, noise while they fly)
+for v in 1 2; do
+PSGDK_ACC_EARLY_EMA=$v timeout 300 python -m pytest tests/test_gpu_kron.py tests/test_gpu_production_path.py -m gpu -q -p no:cacheprovider -x \
+    -k "kwns4_step or kronwhiten or functional_seam or fp32 or small_full_plan and True" > $OUT/pytest_early_ema$v.log 2>&1; echo "exit $?" >> $OUT/pytest_early_ema$v.log
+done
+for v in 0 1 2; do
   ( cd /tmp && PSGDK_ACC_EARLY_EMA=$v rocprofv3 --kernel-trace --stats -d /tmp/p_e$v -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > $R/$OUT/bench_early_ema$v.json 2>> $R/$OUT/rocprof.err
     db=$(find /tmp/p_e$v -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/step_sequence_early_ema$v.md )
 done
-tail -3 $OUT/pytest_early_ema.log; for v in 0 1; do echo early_ema=$v; grep accumulate $OUT/step_sequence_early_ema$v.md; tail -1 $OUT/step_sequence_early_ema$v.md; done
+tail -3 $OUT/pytest_early_ema1.log; tail -3 $OUT/pytest_early_ema2.log; for v in 0 1 2; do echo early_ema=$v; grep accumulate $OUT/step_sequence_early_ema$v.md; tail -1 $OUT/step_sequence_early_ema$v.md; done
 tail -25 $OUT/nlb_stamps_bf16_768.txt; tail -3 $OUT/pytest_ksplit.log; tail -3 $OUT/pytest_ksplit_fuzz.log
 python - <<'EOF'
 import json
