@@ -24,7 +24,7 @@ import torch
 
 from . import _lib as L
 from .engine import KronEngine
-from .sharding import chunk_partition, lpt_partition, kron_step_cost
+from .sharding import assign_owners, chunk_partition, lpt_partition, kron_step_cost
 
 
 _GEOMETRIES = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"}      # psgd.py:161 (init_kron's dQ)
@@ -170,6 +170,8 @@ class KWNS4(torch.optim.Optimizer):
         self._split_pd = {}
         self._split_owner = {}       # sharded mode: owner rank of every split-off parameter (kept from the batched bucket)
         self._pos_cache = {}
+        self._owners = {}            # chunked buckets: bucket key -> {position of the parameter in its group: owner rank}
+        self._legacy_owners = False  # a checkpoint of rounds 1-3 (owners chosen chunk by chunk) was loaded: keep that rule
 
     # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
     # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
@@ -232,14 +234,25 @@ class KWNS4(torch.optim.Optimizer):
             costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
             part = chunk_partition(costs, self._shard_chunks, self.world)         # deterministic: the same on every rank
             ch = self._chunks[key] = {pos[id(p)]: c for p, c in zip(plist, part)}
+            if not self._legacy_owners:
+                # owners over ALL chunks at once (every rank's total, not each chunk's slowest rank, bounds the arithmetic: the
+                # exchanges are asynchronous); part of the checkpoint like the chunk map
+                own = assign_owners(costs, part, self._shard_chunks, self.world)
+                self._owners[key] = {pos[id(p)]: r for p, r in zip(plist, own)}
+        own = self._owners.get(key)
         out = []
         for c in range(self._shard_chunks):
             sub = [p for p in plist if ch.get(pos[id(p)], 0) == c]     # (a parameter first seen later joins chunk 0, which then splits)
             if sub:
-                out += self._buckets_for_key(gi, group, sub, key + ("c", c))
+                out += self._buckets_for_key(gi, group, sub, key + ("c", c), own)
         return out
 
-    def _buckets_for_key(self, gi: int, group, plist: List[torch.Tensor], key):
+    def _buckets_for_key(self, gi: int, group, plist: List[torch.Tensor], key, own=None):
+        """own: {position in the group: owner rank} decided for the whole (chunked) bucket, or None (owners by the per-bucket greedy)"""
+        def owners_of(ps):
+            if own is None or any(pos[id(p)] not in own for p in ps):
+                return None
+            return [own[pos[id(p)]] for p in ps]
         pos = self._pos(gi, group)
         if key in self._split:
             out = []
@@ -260,11 +273,11 @@ class KWNS4(torch.optim.Optimizer):
                 def _dt(x):
                     return None if x in (None, "None") else getattr(torch, x.split(".")[-1])
                 b = self._bucket_for(gi, group, had, key=key, shapes=[tuple(self._data_of(p).squeeze().shape) for p in had],
-                                     pd=_dt(saved.get("pd")))
+                                     pd=_dt(saved.get("pd")), owner=owners_of(had))
         if b is not None and b.param_ids != tuple(map(id, plist)):
             self._split_bucket(gi, group, key, b, pos)
-            return self._buckets_for_key(gi, group, plist, key)
-        return [(self._bucket_for(gi, group, plist, key=key), plist)]
+            return self._buckets_for_key(gi, group, plist, key, own)
+        return [(self._bucket_for(gi, group, plist, key=key, owner=owners_of(plist)), plist)]
 
     def _split_bucket(self, gi, group, key, b, pos):
         self._split.add(key)
@@ -343,6 +356,11 @@ class KWNS4(torch.optim.Optimizer):
             per_rank = [sum(pad8[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
             seg = max(per_rank + [8])
             b.seg = seg
+            # what each rank really has to send (elements at the head of its segment).  A dominant tensor (GPT-2's wte: 38.6 M of the
+            # 124 M elements, owned by ONE rank) makes its chunk's equal-size segments mostly padding: at 8 ranks the padded gathers
+            # of a GPT-2-small step deliver 714 MB to every rank where 225 MB are preconditioned gradients
+            b.used = per_rank
+            b.uneven = seg * self.world > 1.25 * sum(per_rank)
             b.flat = torch.zeros(self.world * seg, dtype=pd, device=p0.device)
             offs = [r * seg for r in range(self.world)]
             b.h_views, h_offsets = [], []
@@ -450,13 +468,20 @@ class KWNS4(torch.optim.Optimizer):
         mine = flat[self.rank * seg:(self.rank + 1) * seg]
         assert flat.is_contiguous() and mine.is_contiguous() and flat.numel() == self.world * seg
         assert mine.data_ptr() == flat.data_ptr() + self.rank * seg * flat.element_size() and mine.dtype == flat.dtype
-        if self._shard_exchange == "p2p":
+        if self._shard_exchange == "p2p" or b.uneven:
+            # exact sizes: every rank sends the used head of its segment to each peer and receives the used heads of theirs (grouped
+            # point-to-point operations: the same code on gloo and RCCL).  Also taken in "all_gather" mode for a chunk whose segments
+            # are more than a quarter padding -- a collective over equal-size segments would move the padding too.
+            used = b.used
             ops = []
             for r in range(self.world):
-                if r != self.rank:
-                    ops.append(torch.distributed.P2POp(torch.distributed.isend, mine, r))
-                    ops.append(torch.distributed.P2POp(torch.distributed.irecv, flat[r * seg:(r + 1) * seg], r))
-            return _Works(torch.distributed.batch_isend_irecv(ops))
+                if r == self.rank:
+                    continue
+                if used[self.rank] > 0:
+                    ops.append(torch.distributed.P2POp(torch.distributed.isend, mine[:used[self.rank]], r))
+                if used[r] > 0:
+                    ops.append(torch.distributed.P2POp(torch.distributed.irecv, flat[r * seg:r * seg + used[r]], r))
+            return _Works(torch.distributed.batch_isend_irecv(ops) if ops else [])
         in_place = torch.distributed.get_backend() == "nccl"
         return torch.distributed.all_gather_into_tensor(flat, mine if in_place else mine.clone(), async_op=True)
 
@@ -536,6 +561,7 @@ class KWNS4(torch.optim.Optimizer):
         return {"psgdk_version": 2, "state": {},      # per-parameter state lives in the bucket arenas below
                 "param_groups": groups, "split": split, "split_owner": split_owner, "shard_chunks": self._shard_chunks,
                 "chunks": [{"parts": parts(k), "of": dict(v)} for k, v in self._chunks.items()],
+                "owners": None if self._legacy_owners else [{"parts": parts(k), "of": dict(v)} for k, v in self._owners.items()],
                 "dQ": self.dQ, "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
 
     def load_state_dict(self, sd):
@@ -567,6 +593,12 @@ class KWNS4(torch.optim.Optimizer):
             self._split_owner[_key(e["parts"])] = list(e["owner"])
         for e in sd.get("chunks", []):
             self._chunks[_key(e["parts"])] = {int(k): int(v) for k, v in e["of"].items()}
+        # owners of chunked buckets: as saved; a checkpoint that has none (rounds 1-3) chose them chunk by chunk -- keep doing so, the
+        # arenas in it belong to those owners
+        self._owners = {}
+        self._legacy_owners = sd.get("owners") is None
+        for e in (sd.get("owners") or []):
+            self._owners[_key(e["parts"])] = {int(k): int(v) for k, v in e["of"].items()}
         for e in sd.get("split", []):
             key = _key(e["parts"])
             if key not in self._split:

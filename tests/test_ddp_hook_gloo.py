@@ -1,5 +1,5 @@
 """The gradient reduce-scatter hook for KWNS4(shard_state=True) (psgd_torch_amd/ddp_hook.py) under a real DistributedDataParallel
-model, world 2, gloo, CPU (TEST-ONLY OracleEngine for the compute): after the first iteration every bucket goes through the uneven
+model, world 2 and 3, gloo, CPU (TEST-ONLY OracleEngine for the compute): after the first iteration every bucket goes through the uneven
 reduce-scatter (all_to_all_single + owner-side sum) instead of an all-reduce, both ranks end with identical parameters, and those equal
 the single-process run on the concatenated batch up to the order of the gradient sums."""
 import os
@@ -62,7 +62,12 @@ def _free_port():
     return port
 
 
-def test_reduce_scatter_hook_matches_single_process():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_hook_matches_single_process(world):
+    """(world 3: six parameters over three owners -- a bucket may hold slices of all three, or none of some rank's: empty splits)"""
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
         sys.path.insert(0, here)
@@ -70,12 +75,15 @@ def test_reduce_scatter_hook_matches_single_process():
     from oracle_engine import OracleEngine
     ref = _model(3)
     opt = psgd_torch_amd.KWNS4(ref.parameters(), engine_factory=OracleEngine, **KW)
-    _train(ref, opt, 5, None, 2)
+    _train(ref, opt, 5, None, world)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
-        r0, r1 = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt"))
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
+    r0 = rs[0]
     assert r0["allreduced"] >= 1 and r0["scattered"] >= 4 * r0["allreduced"] > 0, (r0["allreduced"], r0["scattered"])   # first iteration only
-    assert sorted(set(r0["owners"])) == [0, 1] and r0["owners"] == r1["owners"]
-    for a, b, c in zip(r0["params"], r1["params"], ref.parameters()):
-        assert torch.equal(a, b), "ranks diverged"
+    assert sorted(set(r0["owners"])) == list(range(world)) and all(r["owners"] == r0["owners"] for r in rs)
+    for k, c in enumerate(ref.parameters()):
+        for r in rs[1:]:
+            assert torch.equal(r0["params"][k], r["params"][k]), "ranks diverged"
+        a = r0["params"][k]
         assert torch.allclose(a, c.detach(), rtol=1e-4, atol=1e-6), float((a - c.detach()).abs().max())

@@ -56,7 +56,8 @@ def _worker(rank, world, port, outdir, kw):
         params = _make(7)
         opt = _run(params, 6 if kw.get("missing") else 4, True, **kw)
         owned = [len(b.owned) for b in opt._buckets.values()]
-        torch.save({"params": [p.data.clone() for p in params], "owned": owned, "n_buckets": len(opt._buckets)},
+        torch.save({"params": [p.data.clone() for p in params], "owned": owned, "n_buckets": len(opt._buckets),
+                    "uneven": [bool(getattr(b, "uneven", False)) for b in opt._buckets.values()]},
                    os.path.join(outdir, f"r{rank}.pt"))
     finally:
         torch.distributed.destroy_process_group()
@@ -93,6 +94,34 @@ def test_sharded_equals_replicated(kw):
         assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
         # (default: 4 chunks per bucket, each with its own exchange; shard_chunks=1: one)
         assert r0["n_buckets"] == min(kw.get("shard_chunks", 4), len(SHAPES)), r0["n_buckets"]
+        # both exchange forms are exercised: one chunk over two ranks is balanced (the collective over equal segments), the small
+        # chunks of the default setting are mostly padding (exact-size point-to-point exchange)
+        if kw.get("shard_chunks") == 1 and kw.get("shard_exchange") != "p2p":
+            assert not any(r0["uneven"]), r0["uneven"]
+        if "shard_chunks" not in kw:
+            assert any(r0["uneven"]), r0["uneven"]
     for a, b, c in zip(r0["params"], r1["params"], ref_params):
         assert torch.equal(a, b), "ranks diverged"
         assert torch.allclose(a, c.data, rtol=0, atol=0), "sharded result differs from the single-process result"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(shard_exchange="p2p", update_preconditioner_first=False), dict(missing=True, resume=True, shard_chunks=2)])
+def test_sharded_world_of_three(kw):
+    """An odd world size: ownership cannot be even (8 tensors over 3 ranks, a rank may own nothing of a chunk), every rank has TWO
+    peers in the point-to-point exchange, and the padded exchange segments differ per chunk.  Same bar as the world-2 test: all ranks
+    bitwise equal, and equal to the single-process run."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    ref_params = _make(7)
+    _run(ref_params, 6 if kw.get("missing") else 4, False, **{k: v for k, v in kw.items() if k != "resume"})
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(3, _free_port(), d, kw), nprocs=3, join=True)
+        rs = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(3)]
+    if not kw.get("missing"):
+        assert sum(sum(r["owned"]) for r in rs) == len(SHAPES)
+    for k, c in enumerate(ref_params):
+        for r in rs[1:]:
+            assert torch.equal(rs[0]["params"][k], r["params"][k]), "ranks diverged"
+        assert torch.equal(rs[0]["params"][k], c.data), "sharded result differs from the single-process result"
