@@ -177,11 +177,27 @@ static unsigned persistent_grid(unsigned n_tiles) {
     return (cus > 0 && n_tiles > (unsigned)cus) ? (unsigned)cus : n_tiles;
 }
 
+// PSGDK_PIPE_SLACK_US=<us> (experiment, off when unset): workgroups of the persistent 256 x 256 launch that walk one tile fewer than the
+// others start that much later (gemm_nt_pipe_kernel<T, true>); returned in units of 16 ticks of the 100 MHz clock, at most 2047
+static unsigned pipe_slack_ticks16() {
+    static const unsigned v = [] {
+        const char* e = getenv("PSGDK_PIPE_SLACK_US");
+        const double us = e ? atof(e) : 0.0;
+        if (!(us > 0.0)) return 0u;
+        const double t = us * 100.0 / 16.0;
+        return (unsigned)(t > 2047.0 ? 2047.0 : (t < 1.0 ? 1.0 : t));
+    }();
+    return v;
+}
+
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
     if (s.big && (s.lock || big_lockstep())) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
-    else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
+    else if (s.big && pipe_slack_ticks16() > 0 && !s.one_per_tile && s.n_tiles < (1u << 20) && persistent_grid(s.n_tiles) < s.n_tiles)
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, true>), dim3(persistent_grid(s.n_tiles)), dim3(512), 0, st, s.d_probs, s.d_tiles,
+                           (int)(s.n_tiles | (pipe_slack_ticks16() << 20)));
+    else if (s.big) hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, false>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
                                        s.d_probs, s.d_tiles, (int)s.n_tiles);
     else if (s.ksplit) hipLaunchKernelGGL(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);

@@ -1,6 +1,6 @@
 #!/bin/bash
-# First GPU call of the next round: the three experiments that were written after round 3's GPU budget was spent (nothing in the default path
-# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~5 minutes of box time.
+# First GPU call of the next round: the four experiments that were written after round 3's GPU budget was spent (nothing in the default path
+# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~7 minutes of box time.
 #   1. tools/nlb_stamps.py -- where the 67 us of a cooperative norm bound go (instrumented instantiation, psgdk_test_nlb_stamps)
 #   2. PSGDK_GEMM_KSPLIT=1 -- 64 x 64 tiles with the K loop split over the waves for stages of few tiles (gemm_nt_ks_kernel): parity on every
 #      small-plan test, then LeNet5's step with and without it, same box
@@ -32,6 +32,15 @@ for v in 0 1 2; do
   ( cd /tmp && PSGDK_ACC_EARLY_EMA=$v rocprofv3 --kernel-trace --stats -d /tmp/p_e$v -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > $R/$OUT/bench_early_ema$v.json 2>> $R/$OUT/rocprof.err
     db=$(find /tmp/p_e$v -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/step_sequence_early_ema$v.md )
 done
+# 4. PSGDK_PIPE_SLACK_US -- the persistent 256 x 256 launch with the workgroups that walk one tile fewer started late (gemm_nt_pipe_kernel<T, true>):
+#    bit-identical outputs (same tiles, same order per workgroup), so one parity run; then the two full-size products' durations at several delays
+PSGDK_PIPE_SLACK_US=14 timeout 200 python -m pytest tests/test_gpu_production_path.py -m gpu -q -p no:cacheprovider -x -k "small_full_plan and True" > $OUT/pytest_slack.log 2>&1; echo "exit $?" >> $OUT/pytest_slack.log
+for us in 0 7 14 21; do
+  ( cd /tmp && PSGDK_PIPE_SLACK_US=$us rocprofv3 --kernel-trace --stats -d /tmp/p_s$us -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > $R/$OUT/bench_slack$us.json 2>> $R/$OUT/rocprof.err
+    db=$(find /tmp/p_s$us -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/step_sequence_slack$us.md )
+  echo slack_us=$us; grep gemm_nt_pipe $OUT/step_sequence_slack$us.md; tail -1 $OUT/step_sequence_slack$us.md
+done
+tail -3 $OUT/pytest_slack.log
 tail -3 $OUT/pytest_early_ema1.log; tail -3 $OUT/pytest_early_ema2.log; for v in 0 1 2; do echo early_ema=$v; grep accumulate $OUT/step_sequence_early_ema$v.md; tail -1 $OUT/step_sequence_early_ema$v.md; done
 tail -25 $OUT/nlb_stamps_bf16_768.txt; tail -3 $OUT/pytest_ksplit.log; tail -3 $OUT/pytest_ksplit_fuzz.log
 python - <<'EOF'
