@@ -2062,6 +2062,13 @@ int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void*
                            if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; LRA_TPR_(tpr_, __VA_ARGS__); }  \
                            else { typedef float T; LRA_TPR_(tpr_, __VA_ARGS__); } } while (0)
 
+// PSGDK_LRA_EARLY_VEC=1 (experiment): the EV instantiations of the row passes (kernels_lra.hiph: N-vector elements requested before the
+// next block's matrix prefetch)
+static bool lra_early_vec() {
+    static const bool v = [] { const char* e = std::getenv("PSGDK_LRA_EARLY_VEC"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of (256 / tpr) x r floats (+ `fixed` bytes of
 // static LDS), and as many workgroups as are resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
 static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm) {
@@ -2105,9 +2112,10 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
                 HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
             hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
         }
-        if constexpr (TPR == 1)
-            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
-        else {      // wider rank classes: the rotation on the fp32 matrix cores (PSGDK_LRA_ROTATE=valu keeps the one-row-per-thread form: A/B)
+        if constexpr (TPR == 1) {
+            if (lra_early_vec()) hipLaunchKernelGGL((lra_rotate_kernel<T, TPR, true>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
+            else hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
+        } else {      // wider rank classes: the rotation on the fp32 matrix cores (PSGDK_LRA_ROTATE=valu keeps the one-row-per-thread form: A/B)
             static const bool valu = [] { const char* e = std::getenv("PSGDK_LRA_ROTATE"); return e && e[0] == 'v'; }();
             if (valu)
                 hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
@@ -2118,12 +2126,24 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
             }
         }
         hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+        if (lra_early_vec())
+            hipLaunchKernelGGL((lra_pass3_kernel<T, TPR, true>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                               Qh, iq, N, r, sm);
+        else
         hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                            Qh, iq, N, r, sm);
         hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+        if (lra_early_vec())
+            hipLaunchKernelGGL((lra_pass4_kernel<T, TPR, true>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                               (const T*)Qh, (const T*)iq, diff, N, r, sm);
+        else
         hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                            (const T*)Qh, (const T*)iq, diff, N, r, sm);
         hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
+        if (lra_early_vec())
+            hipLaunchKernelGGL((lra_pass5_kernel<T, TPR, true>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+                               N, r, update_u ? 1 : 0, (const float*)sm);
+        else
         hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                            N, r, update_u ? 1 : 0, (const float*)sm);
     });
@@ -2142,9 +2162,14 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
     LRA_T(L, {
         HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
         T* y = (T*)(L->work + L->y_off);
-        for (int stage = 0; stage < 3; ++stage)
+        for (int stage = 0; stage < 3; ++stage) {
+            if (lra_early_vec())
+                hipLaunchKernelGGL((lra_apply_kernel<T, TPR, true>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+                                   (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
+            else
             hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                                (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
+        }
     });
     HIPCHK(hipGetLastError());
     return PSGDK_OK;

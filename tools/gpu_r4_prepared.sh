@@ -1,6 +1,6 @@
 #!/bin/bash
-# First GPU call of the next round: the four experiments that were written after round 3's GPU budget was spent (nothing in the default path
-# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~7 minutes of box time.
+# First GPU call of the next round: the five experiments that were written after round 3's GPU budget was spent (nothing in the default path
+# uses them; tools/isa_fingerprint.py check shows the production kernels unchanged).  ~9 minutes of box time.
 #   1. tools/nlb_stamps.py -- where the 67 us of a cooperative norm bound go (instrumented instantiation, psgdk_test_nlb_stamps)
 #   2. PSGDK_GEMM_KSPLIT=1 -- 64 x 64 tiles with the K loop split over the waves for stages of few tiles (gemm_nt_ks_kernel): parity on every
 #      small-plan test, then LeNet5's step with and without it, same box
@@ -40,6 +40,15 @@ for us in 0 7 14 21; do
     db=$(find /tmp/p_s$us -name "*.db" | head -1); python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $R/$OUT/step_sequence_slack$us.md )
   echo slack_us=$us; grep gemm_nt_pipe $OUT/step_sequence_slack$us.md; tail -1 $OUT/step_sequence_slack$us.md
 done
+# 5. PSGDK_LRA_EARLY_VEC=1 -- the LRA row passes with the block's N-vector elements requested before the next block's matrix prefetch
+#    (EV instantiations): parity on the LRA suite, then ViT-B r = 10 with and without it, per-kernel durations
+PSGDK_LRA_EARLY_VEC=1 timeout 300 python -m pytest tests/test_gpu_lra.py tests/test_gpu_fullsize.py -m gpu -q -p no:cacheprovider -x -k "lra and not true_n" > $OUT/pytest_lra_ev.log 2>&1; echo "exit $?" >> $OUT/pytest_lra_ev.log
+for v in 0 1; do
+  ( cd /tmp && PSGDK_LRA_EARLY_VEC=$v rocprofv3 --kernel-trace --stats -d /tmp/p_l$v -- python $R/bench.py --config vit-b-lra --steps 5 --warmup 2 --no-cpu-baseline --no-peaks > $R/$OUT/bench_lra_ev$v.json 2>> $R/$OUT/rocprof.err
+    db=$(find /tmp/p_l$v -name "*.db" | head -1); python $R/tools/rocpd_stats.py $db > $R/$OUT/lra_kernel_stats_ev$v.md )
+  echo lra_early_vec=$v; grep "lra_" $OUT/lra_kernel_stats_ev$v.md | head -8
+done
+tail -3 $OUT/pytest_lra_ev.log
 tail -3 $OUT/pytest_slack.log
 tail -3 $OUT/pytest_early_ema1.log; tail -3 $OUT/pytest_early_ema2.log; for v in 0 1 2; do echo early_ema=$v; grep accumulate $OUT/step_sequence_early_ema$v.md; tail -1 $OUT/step_sequence_early_ema$v.md; done
 tail -25 $OUT/nlb_stamps_bf16_768.txt; tail -3 $OUT/pytest_ksplit.log; tail -3 $OUT/pytest_ksplit_fuzz.log
