@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 300    /* round 3: test hooks moved to psgdk_test.h, psgdk_test_dump_noise; (200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
+#define PSGDK_VERSION 400    /* round 4: row shards (psgdk_plan_set_row_shard, psgdk_update_precond_begin / _finish, psgdk_balance_phase),
+                                psgdk_profile_read_calls; (300: test hooks moved to psgdk_test.h; 200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
 #define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
 
 /* status codes */
@@ -255,13 +256,46 @@ int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr);
 #define PSGDK_INFO_NLB_FALLBACKS 1
 #define PSGDK_INFO_DENSE_FACTORS 2
 #define PSGDK_INFO_MAX_DENSE_DIM 3   /* padded to a multiple of 64 */
+#define PSGDK_INFO_HSUMSQ_OFFSET 4   /* byte offset in the WORK arena of the fp32 sums of h^2, one per tensor (written by psgdk_precond_grad,
+                                        read by the clip of psgdk_apply_update / psgdk_export_precond_grad): a row shard's entry is summed
+                                        over the members by the caller in between */
+#define PSGDK_INFO_BALNORM_OFFSET 5  /* byte offset in the WORK arena of the balancing slots of psgdk_balance_phase */
 int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
+
+/* ---- row shards: the sharded (multi-GPU) path's split of a DOMINANT tensor (new; the reference only replicates -- SURVEY 8e.  GPT-2's
+ * tied embedding is 31 % of the model's elements and 20 % of a step's FLOPs: owned by one rank it caps the scaling of everything).
+ * Tensor t of this plan is declared to be rows [row0, row0 + rows_t) of a (global_rows x cols) matrix whose dim-0 factor is diagonal and
+ * whose dim-1 factor is dense (psgd.py:208 applied to the WHOLE matrix); `members` plans, one per rank, hold the blocks.  Then
+ *   - term2 = numel / size (psgd.py:407,412) and the RMS clip (..._ddp.py:153-155) use the whole matrix's element count; the damping
+ *     noise's Philox counters run over the whole matrix (a shard draws what one GPU would);
+ *   - the dense factor is REPLICATED on the members and fitted to the whole matrix: the update is cut in two halves around ONE exchange,
+ *     psgdk_update_precond_begin ... all-gather of `exchange` ... psgdk_update_precond_finish.  `exchange` holds `members` records of
+ *     psgdk_plan_exchange_bytes() bytes each (256-byte aligned; record m written by member m's begin): per shard the fp32 partial mode
+ *     Gram sum_rows Pg^T Pg (psgd.py:405) and the member's max of the diagonal factor's term1 (psgd.py:408).  finish sums the partial
+ *     Grams in member order (identical bits on every member), rounds once, and continues with psgd.py:406-416; the diagonal factor's rows
+ *     are updated locally with the maximum over all members;
+ *   - balancing (psgd.py:418, 266-275) of a shard needs max |q| over all members' rows: psgdk_balance_phase(0), caller's max over the
+ *     members of the 2 floats per shard at PSGDK_INFO_BALNORM_OFFSET, psgdk_balance_phase(1); psgdk_update_precond_finish ignores the
+ *     balance flags of shards;
+ *   - psgdk_precond_grad leaves the shard's OWN sum of h^2 at PSGDK_INFO_HSUMSQ_OFFSET + 4 t: the caller sums it over the members before
+ *     psgdk_export_precond_grad / psgdk_apply_update clip.
+ * Q0.5EQ1.5 geometry only; before psgdk_plan_bind.  The one-call psgdk_update_precond_q0p5eq1p5 refuses a plan with shards. */
+int psgdk_plan_set_row_shard(psgdk_plan* plan, int t, int64_t global_rows, int64_t row0, int member, int members);
+int psgdk_plan_exchange_bytes(const psgdk_plan* plan, size_t* record_bytes);
+int psgdk_update_precond_begin(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
+                               uint64_t offset, void* exchange, void* stream);
+int psgdk_update_precond_finish(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
+                                uint64_t offset, const void* exchange, const uint8_t* balance_mask, void* stream);
+int psgdk_balance_phase(psgdk_plan* plan, const uint8_t* mask, int phase, void* stream);
 
 /* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): when enabled, every gemm_nt launch is
  * bracketed by hipEvents on the launch stream; psgdk_profile_read synchronises those events and returns the summed
  * launch time (ms) and the launch count since the last reset. */
 int psgdk_profile_enable(psgdk_plan* plan, int enable);
 int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset);
+/* the same switch also brackets every hot-path CALL (accumulate, update, precond_grad, apply / export) by an event pair: the summed device
+ * time between the first and the last kernel of each call, i.e. the engine's kernel time per step without the host in it. */
+int psgdk_profile_read_calls(psgdk_plan* plan, double* call_ms, int64_t* calls, int reset);
 
 /* Kernel-level test / benchmark hooks (psgdk_test_*) are declared in psgdk_test.h: exported by the same library, not part of the
  * drop-in surface. */

@@ -7,12 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE, PSGDK_ERR_NLB_TIMEOUT = 0, 1, 2, 3, 4, 5
-INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM = 0, 1, 2, 3
+INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM, INFO_HSUMSQ_OFFSET, INFO_BALNORM_OFFSET = 0, 1, 2, 3, 4, 5
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 300      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 400      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -86,6 +86,14 @@ SIGNATURES = {
     "psgdk_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "psgdk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "psgdk_profile_read_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "psgdk_plan_set_row_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "psgdk_plan_exchange_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "psgdk_update_precond_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Noise), C.c_uint64, C.c_uint64,
+                                             C.c_void_p, C.c_void_p]),
+    "psgdk_update_precond_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(Noise), C.c_uint64, C.c_uint64,
+                                              C.c_void_p, C.POINTER(C.c_uint8), C.c_void_p]),
+    "psgdk_balance_phase": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_void_p]),
     "psgdk_flat_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "psgdk_flat_destroy": (C.c_int, [C.c_void_p]),
     "psgdk_flat_apply": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
@@ -103,6 +111,7 @@ TEST_SIGNATURES = {
     "psgdk_test_dump_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "psgdk_test_peaks": (C.c_int, [C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "psgdk_test_clock": (C.c_int, [C.POINTER(C.c_float), C.c_void_p]),
     "psgdk_test_nlb_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "psgdk_test_nlb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

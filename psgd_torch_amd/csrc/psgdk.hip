@@ -27,7 +27,9 @@ struct Stage {                       // one grouped GEMM launch
     bool lock = false;               // tests / experiments: the lock-step main loop of the 256x256 tiling
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
-    bool ksplit = false;             // small plans (PSGDK_GEMM_KSPLIT): 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
+    bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
+    bool mid = false;                // 256 x 128 / 8-wave persistent tiling (gemm_nt_mid_kernel)
+    bool late_f2 = false;            // experiment: its LATE_F2 instantiation
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -76,20 +78,26 @@ struct psgdk_plan {
     // (read at the start of every update call; see nlb_check_error)
     volatile unsigned* h_err = nullptr; unsigned* d_err = nullptr;
     int64_t nlb_fallbacks = 0;        // how often a timeout moved this plan to the multi-launch route (0 or 1)
-    bool nlb_narrow = false;         // PSGDK_NLB_WIDE=0: the 4-byte publish stores of rounds 1-2 (A/B)
     bool nlb_unfused = false;        // PSGDK_NLB_FUSED=0 at plan creation: keep the multi-launch route (tests compare the two)
     bool p_valid = false;
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
+    // row shards (psgdk_plan_set_row_shard): tensors of this plan that are row blocks of a larger, row-sharded tensor.  Their dense
+    // factor is replicated on the `members` owners of the blocks and fitted to the WHOLE tensor: the members' partial mode Grams
+    // (fp32) and their maxima of the diagonal factor's term1 are exchanged between the two halves of a phased update.
+    struct RowShard { int tensor; int64_t global_rows, row0; size_t rec_off; };
+    std::vector<RowShard> shards;
+    int shard_member = 0, shard_members = 0;
+    size_t xchg_record_bytes = 0;                    // one member's record: per shard [dp x dp fp32 partial Gram][64 fp32 scalars]
+    bool update_open = false;                        // between psgdk_update_precond_begin and _finish
+    int shard_of(int t) const { for (size_t i = 0; i < shards.size(); ++i) if (shards[i].tensor == t) return (int)i; return -1; }
     // PSGDK_GEOM_EQ (psgd.py:278-336): A = (kron Q) Hvp in two products, Grams of A and B, Q -= mu triu(.) Q; the right
     // triangular solves run in two phases (column-side factors on V, then row-side factors on the transposed result)
     int geometry = PSGDK_GEOM_Q0P5EQ1P5;
     bool p_mode() const { return geometry == PSGDK_GEOM_QUAD4P || geometry == PSGDK_GEOM_PRO4P; }   // the factors ARE P (psgd.py:422-452, 486-513)
-    // default geometry: the update + Procrustes chain runs in transposed space (see psgdk_plan_bind); PSGDK_CHAIN=legacy keeps the
-    // round-2 Q-space chain (A/B runs and the bit-for-bit comparison of the two)
-    bool chain_legacy = false;
-    bool chain_t() const { return geometry == PSGDK_GEOM_Q0P5EQ1P5 && !chain_legacy; }
+    // default geometry: the update + Procrustes chain runs in transposed space (see psgdk_plan_bind)
+    bool chain_t() const { return geometry == PSGDK_GEOM_Q0P5EQ1P5; }
     Stage e_a1, e_a2, e_g1, e_g2, e_qupd;
     Stage v_qeq, v_quad2;                            // PSGDK_GEOM_QEQ: Q term1;  PSGDK_GEOM_QUAD: the second half step
     Stage v_qep_u, v_qep_t1, v_qep_t2;               // PSGDK_GEOM_QEP: Q term1, (Q term1) Q^T, c Q Q^T
@@ -100,8 +108,8 @@ struct psgdk_plan {
     UinvJob* d_uinv = nullptr; unsigned n_uinv = 0;
     // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
     bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
-    size_t prof_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev, prof_call_ev;
+    size_t prof_used = 0, prof_call_used = 0;
 
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
@@ -115,6 +123,7 @@ struct psgdk_plan {
         fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag);
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : prof_call_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
         fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_ts);
@@ -135,8 +144,8 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
-    tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
-    tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
+    tb.bm = s.big ? GEMM_BIG_BM : (s.mid ? GEMM_MID_BM : (s.ksplit ? 64 : GEMM_BM));
+    tb.bn = s.big ? GEMM_BIG_BN : (s.mid ? GEMM_MID_BN : (s.ksplit ? 64 : GEMM_BN));
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
@@ -145,31 +154,26 @@ int finish_stage(Stage& s) {
     return upload(&s.d_tiles, tiles);
 }
 
-// experiment switches (read once): PSGDK_GEMM_BIG=lock selects the lock-step main loop of the 256 x 256 tiling instead of the
-// staggered-phase one; PSGDK_BIG_MIN_TILES moves the number of 256 x 256 tiles from which a stage uses that tiling
-static bool big_lockstep() {
-    static const int v = [] { const char* e = getenv("PSGDK_GEMM_BIG"); return (e && e[0] == 'l') ? 1 : 0; }();
-    return v != 0;
-}
-// PSGDK_GEMM_KSPLIT=n (experiment, off when unset): a stage whose problems make at most n tiles of 128 x 128 ("1" = 64) runs on 64 x 64
-// tiles with the K loop split over the workgroup's waves (gemm_nt_ks_kernel)
-static int64_t ksplit_max_tiles() {   // (read at every bind)
-    const char* e = getenv("PSGDK_GEMM_KSPLIT");
-    if (!e || !e[0] || e[0] == '0') return 0;
+// A stage whose problems make at most this many tiles of 128 x 128 runs on 64 x 64 tiles with the K loop split over the workgroup's waves
+// (gemm_nt_ks_kernel; round 4, measured: LeNet5's step 0.234 -> 0.195 ms, profiles/r04_a_ksplit.md)
+static constexpr int64_t kKsplitMaxTiles = 64;
+// PSGDK_GEMM_MID (experiment while it is being measured; read at every bind): "1" = stages of at least 512 tiles of 256 x 128 that do not
+// take the 256 x 256 tiling run on gemm_nt_mid_kernel; a number = that threshold
+static int64_t mid_min_tiles() {
+    const char* e = getenv("PSGDK_GEMM_MID");
+    if (!e || !e[0] || e[0] == '0') return -1;
     const int64_t v = atoll(e);
-    return v <= 1 ? 64 : v;
+    return v <= 1 ? 512 : v;
 }
 static int64_t big_min_tiles() {      // (read at every bind: the tests force the big tiling onto small plans with it)
     const char* e = getenv("PSGDK_BIG_MIN_TILES");
     return e ? (int64_t)atoll(e) : (int64_t)768;
 }
 
-// the staggered-phase kernel runs persistently (one workgroup per CU walks the tile table) unless PSGDK_GEMM_PERSIST=0 or the
-// stage asks for one workgroup per tile (experiments)
+// the staggered-phase kernel runs persistently (one workgroup per CU walks the tile table) unless the stage asks for one workgroup
+// per tile (test hook)
 static unsigned persistent_grid(unsigned n_tiles) {
     static const int cus = [] {
-        const char* e = getenv("PSGDK_GEMM_PERSIST");
-        if (e && e[0] == '0') return 0;
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         return n - n % 8;          // a multiple of 8: a workgroup's stride keeps it on one XCD's queue of the interleaved table
@@ -177,28 +181,16 @@ static unsigned persistent_grid(unsigned n_tiles) {
     return (cus > 0 && n_tiles > (unsigned)cus) ? (unsigned)cus : n_tiles;
 }
 
-// PSGDK_PIPE_SLACK_US=<us> (experiment, off when unset): workgroups of the persistent 256 x 256 launch that walk one tile fewer than the
-// others start that much later (gemm_nt_pipe_kernel<T, true>); returned in units of 16 ticks of the 100 MHz clock, at most 2047
-static unsigned pipe_slack_ticks16() {
-    static const unsigned v = [] {
-        const char* e = getenv("PSGDK_PIPE_SLACK_US");
-        const double us = e ? atof(e) : 0.0;
-        if (!(us > 0.0)) return 0u;
-        const double t = us * 100.0 / 16.0;
-        return (unsigned)(t > 2047.0 ? 2047.0 : (t < 1.0 ? 1.0 : t));
-    }();
-    return v;
-}
-
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
-    if (s.big && (s.lock || big_lockstep())) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
-    else if (s.big && pipe_slack_ticks16() > 0 && !s.one_per_tile && s.n_tiles < (1u << 20) && persistent_grid(s.n_tiles) < s.n_tiles)
-        hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, true>), dim3(persistent_grid(s.n_tiles)), dim3(512), 0, st, s.d_probs, s.d_tiles,
-                           (int)(s.n_tiles | (pipe_slack_ticks16() << 20)));
-    else if (s.big) hipLaunchKernelGGL((gemm_nt_pipe_kernel<T, false>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
+    if (s.big && s.lock) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
+    else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
                                        s.d_probs, s.d_tiles, (int)s.n_tiles);
+    else if (s.mid && s.late_f2) hipLaunchKernelGGL((gemm_nt_mid_kernel<T, true>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
+                                                    s.d_probs, s.d_tiles, (int)s.n_tiles);
+    else if (s.mid) hipLaunchKernelGGL((gemm_nt_mid_kernel<T, false>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st, s.d_probs,
+                                       s.d_tiles, (int)s.n_tiles);
     else if (s.ksplit) hipLaunchKernelGGL(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
@@ -217,6 +209,21 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
     if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st); else launch_stage_t<float>(s, st);
     if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used++].second, st);
 }
+
+// profiling (psgdk_profile_enable): an event pair around one hot-path call -- recorded on entry and when the call returns
+struct ProfCall {
+    psgdk_plan* p; hipStream_t st; bool on;
+    ProfCall(psgdk_plan* plan, void* stream) : p(plan), st((hipStream_t)stream), on(plan && plan->prof && plan->state) {
+        if (!on) return;
+        if (p->prof_call_used == p->prof_call_ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            p->prof_call_ev.emplace_back(a, b);
+        }
+        (void)hipEventRecord(p->prof_call_ev[p->prof_call_used].first, st);
+    }
+    ~ProfCall() { if (on) (void)hipEventRecord(p->prof_call_ev[p->prof_call_used++].second, st); }
+};
 
 #define DISPATCH_T(plan, CALL)                         \
     do {                                               \
@@ -319,7 +326,7 @@ static void layout_arenas(psgdk_plan* P) {
         F.slab_off = 0; F.gpart_off = 0;
         if (D.kind == TK_GEN) { F.gpart_off = wo; wo += align256((size_t)PSGDK_GEN_GPART * 4); }
         if (P->geometry == PSGDK_GEOM_EQ) { F.uinv_off = wo; wo += align256((size_t)F.dp * 64 * 4); }
-        if (D.kind != TK_GEN && K > 4096) {
+        if (D.kind != TK_GEN && (K > 4096 || P->shard_of(F.tensor) >= 0)) {      // (a row shard's Gram always leaves as fp32 partials)
             const int nks = (K + 3071) / 3072;
             F.slab_off = wo; wo += align256((size_t)nks * F.dp * F.dp * 4);
         }
@@ -367,7 +374,6 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
     P->esz = precond_dtype == PSGDK_BF16 ? 2 : 4;
     P->max_size = max_size; P->max_skew = max_skew;
     { const char* e = getenv("PSGDK_NLB_FUSED"); P->nlb_unfused = e && e[0] == '0'; }
-    { const char* e = getenv("PSGDK_CHAIN"); P->chain_legacy = e && e[0] == 'l'; }
     size_t dpos = 0;
     // ---- structure (init_kron's dense/diag rule) ----
     for (int t = 0; t < n_tensors; ++t) {
@@ -418,6 +424,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
             fr.push_back(FactorRef{d1 ? PSGDK_DENSE : PSGDK_DIAG, -1});
         }
         D.stream_id = (unsigned)t;
+        D.numel_clip = numel; D.row0 = 0;
         D.wide = (!D.transposed && D.C >= 256 && D.R >= 4) ? 1 : 0;
         P->td.push_back(D);
         P->factors.push_back(fr);
@@ -452,6 +459,7 @@ int psgdk_plan_create(psgdk_plan** out, int n_tensors, const int32_t* ndim, cons
                 P->max_dp = std::max(P->max_dp, F.dp);
             } else {
                 DiagDesc G{};
+                G.ext_max_off = -1;
                 G.tensor = t; G.len = len; G.is_row = is_row ? 1 : 0;
                 G.c = (float)((double)D.numel / (double)len);
                 fr[i].idx = (int)P->dd.size();
@@ -480,8 +488,44 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
     if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_PRO4P) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
+    if (!plan->shards.empty() && geometry != PSGDK_GEOM_Q0P5EQ1P5) return PSGDK_ERR_UNSUPPORTED;
     plan->geometry = geometry;
     layout_arenas(plan);
+    return PSGDK_OK;
+}
+
+int psgdk_plan_set_row_shard(psgdk_plan* plan, int t, int64_t global_rows, int64_t row0, int member, int members) {
+    if (!plan || t < 0 || t >= plan->n_tensors || members < 2 || member < 0 || member >= members) return PSGDK_ERR_INVALID;
+    if (plan->state) return PSGDK_ERR_STATE;
+    if (plan->geometry != PSGDK_GEOM_Q0P5EQ1P5) return PSGDK_ERR_UNSUPPORTED;
+    TensorDesc& D = plan->td[t];
+    // a row block of a matrix with a diagonal factor on dim 0 and a dense one on dim 1, held as it is (rows contiguous in the caller's
+    // tensor): the structure init_kron gives the WHOLE tensor must also be what the block got from its own shape (the host checks that
+    // before it splits a tensor; here it is verified)
+    if (D.kind != TK_M1 || D.transposed || D.row_diag < 0 || D.col_dense < 0) return PSGDK_ERR_INVALID;
+    if (row0 < 0 || global_rows <= 0 || row0 + D.lrows > global_rows || plan->shard_of(t) >= 0) return PSGDK_ERR_INVALID;
+    if (!plan->shards.empty() && (plan->shard_member != member || plan->shard_members != members)) return PSGDK_ERR_INVALID;
+    if (!is_dense_dim(D.lcols, global_rows * D.lcols, plan->max_size, plan->max_skew) ||
+        is_dense_dim(global_rows, global_rows * D.lcols, plan->max_size, plan->max_skew)) return PSGDK_ERR_INVALID;
+    plan->shard_member = member; plan->shard_members = members;
+    const double numel_g = (double)global_rows * (double)D.lcols;
+    D.numel_clip = (long long)(global_rows * (int64_t)D.lcols);
+    D.row0 = row0;
+    plan->dd[D.row_diag].c = (float)(numel_g / (double)global_rows);
+    plan->dn[D.col_dense].c = (float)(numel_g / (double)D.lcols);
+    size_t ro = 0;
+    for (auto& sh : plan->shards) ro = sh.rec_off + align256((size_t)plan->dn[plan->td[sh.tensor].col_dense].dp * plan->dn[plan->td[sh.tensor].col_dense].dp * 4 + 256);
+    plan->shards.push_back(psgdk_plan::RowShard{t, global_rows, row0, ro});
+    const int dp = plan->dn[D.col_dense].dp;
+    plan->dd[D.row_diag].ext_max_off = (long long)(ro + (size_t)dp * dp * 4);
+    plan->xchg_record_bytes = ro + align256((size_t)dp * dp * 4 + 256);
+    layout_arenas(plan);
+    return PSGDK_OK;
+}
+
+int psgdk_plan_exchange_bytes(const psgdk_plan* plan, size_t* record_bytes) {
+    if (!plan || !record_bytes) return PSGDK_ERR_INVALID;
+    *record_bytes = plan->xchg_record_bytes;
     return PSGDK_OK;
 }
 
@@ -860,9 +904,20 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
         // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
-        // small plans (experiment): few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
+        // the middle tiling for what stays off the 256 x 256 one: many problems of moderate size (the 62 x 768^3 stages of GPT-2-small)
+        s->mid = false;
+        if (const int64_t mmin = mid_min_tiles(); mmin > 0 && !s->big && !s->ext && !s->probs.empty()) {
+            int64_t nm = 0;
+            for (const GemmProblem& g : s->probs) {
+                const int64_t tm = (g.M + GEMM_MID_BM - 1) / GEMM_MID_BM, tn = (g.N + GEMM_MID_BN - 1) / GEMM_MID_BN;
+                const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+                nm += ((g.flags & GF_SYM) ? (tm * tn + tm) / 2 : tm * tn) * nks;       // (symmetric: roughly the upper half)
+            }
+            s->mid = nm >= mmin;
+        }
+        // small launches: few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
         s->ksplit = false;
-        if (const int64_t kmax = ksplit_max_tiles(); kmax > 0 && !s->big && !s->ext && !s->probs.empty()) {
+        if (!s->big && !s->mid && !s->ext && !s->probs.empty()) {
             const int bk = P->dtype == PSGDK_BF16 ? 64 : 32;
             int64_t n128 = 0;
             bool ok = true;
@@ -873,7 +928,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 ok = ok && g.M % 64 == 0 && g.N % 64 == 0 && g.K % bk == 0 && g.K >= bk &&
                      (!(g.flags & GF_SPLITK) || g.kchunk % bk == 0);
             }
-            s->ksplit = ok && n128 <= kmax;
+            s->ksplit = ok && n128 <= kKsplitMaxTiles;
         }
     }
     for (Stage* s : P->all_stages())
@@ -918,8 +973,8 @@ static int run_balance(psgdk_plan* P, const uint8_t* balance_mask, hipStream_t s
     if (balance_mask) {
         std::vector<int>& which = P->h_balance;      // plan-owned staging for the async upload
         which.clear();
-        for (int t = 0; t < P->n_tensors; ++t)
-            if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN) which.push_back(t);
+        for (int t = 0; t < P->n_tensors; ++t)      // (row shards: psgdk_balance_phase, around the caller's max over the members)
+            if (balance_mask[t] && P->factors[t].size() > 1 && P->td[t].kind != TK_GEN && P->shard_of(t) < 0) which.push_back(t);
         for (size_t gi = 0; gi < P->gd.size(); ++gi)
             if (balance_mask[P->gd[gi].tensor])
                 DISPATCH_T(P, hipLaunchKernelGGL(gen_balance_kernel<T>, dim3(1), dim3(256), 0, st, P->d_gd, (int)gi, P->d_dd, P->d_dn, P->state));
@@ -951,6 +1006,7 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
                      int param_dtype, float coupled_wd, float beta, int keep_grad, const psgdk_damp* damp, void* stream) {
     if (!plan || !grads) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
+    ProfCall prof_call(plan, stream);
     if ((grad_dtype != PSGDK_BF16 && grad_dtype != PSGDK_F32) || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (coupled_wd != 0.f && !params) return PSGDK_ERR_INVALID;
     if (!(beta >= 0.f && beta < 1.f)) return PSGDK_ERR_INVALID;
@@ -976,24 +1032,12 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
         }
         do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
     }
-    static const int early_ema = [] { const char* e = getenv("PSGDK_ACC_EARLY_EMA"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();   // experiment
-#define PSGDK_ACC_ARGS dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,                                                      \
-                       plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,                              \
-                       plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,              \
-                       do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0,                     \
-                       (unsigned long long)plan->hsumsq_off, (unsigned)plan->n_tensors,                                           \
-                       (unsigned long long)plan->zero_off, (unsigned long long)(damp ? plan->zero_bytes : 0)
-    if (early_ema == 2) {
-        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 2>), PSGDK_ACC_ARGS);
-        else hipLaunchKernelGGL((accumulate_kernel<float, 2>), PSGDK_ACC_ARGS);
-    } else if (early_ema == 1) {
-        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 1>), PSGDK_ACC_ARGS);
-        else hipLaunchKernelGGL((accumulate_kernel<float, 1>), PSGDK_ACC_ARGS);
-    } else {
-        if (plan->dtype == PSGDK_BF16) hipLaunchKernelGGL((accumulate_kernel<bf16_t, 0>), PSGDK_ACC_ARGS);
-        else hipLaunchKernelGGL((accumulate_kernel<float, 0>), PSGDK_ACC_ARGS);
-    }
-#undef PSGDK_ACC_ARGS
+    DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
+                                        plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,
+                                        plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
+                                        do_x, x_from_grad, damping, ng, seed, offset, plan->geometry == PSGDK_GEOM_EQ ? 1 : 0,
+                                        (unsigned long long)plan->hsumsq_off, (unsigned)plan->n_tensors,
+                                        (unsigned long long)plan->zero_off, (unsigned long long)(damp ? plan->zero_bytes : 0)));
     HIPCHK(hipGetLastError());
     // this pass also cleared the sums of h^2 (the precond_grad of this step) and, when an update was announced, that update's
     // accumulators (row sums, scalars, arrival counters, balancing norms): one memset launch less for each
@@ -1061,10 +1105,8 @@ static int nlb_plan_coop(psgdk_plan* P) {
     P->n_nlb_jobs = (unsigned)n_jobs;
     // the subspace block (32 rows of the widest factor + 16 bytes each) + eight wave-private publish stages of 32 x (32 T + 16 bytes)
     P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16) + 8 * 32 * (32 * P->esz + 16));
-    { const char* e = getenv("PSGDK_NLB_WIDE"); P->nlb_narrow = e && e[0] == '0'; }
-    for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
-                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, false>, (const void*)nlb_coop_kernel<float, 2, 24, false>,
-                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, true, true>, (const void*)nlb_coop_kernel<float, 2, 24, true, true>})
+    for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24>, (const void*)nlb_coop_kernel<float, 2, 24>,
+                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
@@ -1073,9 +1115,8 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
                    int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0, bool stamps = false) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
-        const void* k = stamps ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true, true> : (const void*)nlb_coop_kernel<float, 2, 24, true, true>)
-                      : P->nlb_narrow ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, false> : (const void*)nlb_coop_kernel<float, 2, 24, false>)
-                                      : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>);
+        const void* k = stamps ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>)
+                               : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
         void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
@@ -1118,11 +1159,19 @@ static int ensure_P(psgdk_plan* plan, hipStream_t st) {
 
 // The three geometries that share Pg = (kron Q^T Q)(G + damped noise), the mode Grams and the spectral-norm step
 // normalisation: Q0.5EQ1.5 (psgd.py:394-419), QEQ (psgd.py:367-391), QUAD (psgd.py:455-483).
+// phase: -1 = the whole update; 0 / 1 = the two halves of a PHASED update of a plan with row shards (psgdk_update_precond_begin / _finish):
+// 0 ends with the members' partial mode Grams and diagonal maxima in record `shard_member` of `xchg`; 1 starts from all members' records.
 static int update_whiten_family(psgdk_plan* plan, int variant, int source, float lr, float betaL, float damping,
                                 const psgdk_noise* noise, uint64_t seed, uint64_t offset,
-                                const uint8_t* balance_mask, void* stream) {
+                                const uint8_t* balance_mask, void* stream, int phase = -1, void* xchg_ = nullptr) {
     if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
     if (!plan->state || plan->geometry != variant) return PSGDK_ERR_STATE;
+    if (phase < 0 && !plan->shards.empty()) return PSGDK_ERR_STATE;         // row shards need the exchange between the two halves
+    if (phase >= 0 && (plan->shards.empty() || !xchg_ || ((uintptr_t)xchg_ & 255))) return PSGDK_ERR_INVALID;
+    if (phase >= 0 && plan->update_open != (phase == 1)) return PSGDK_ERR_STATE;
+    unsigned char* xchg = (unsigned char*)xchg_;
+    const bool do_a = phase != 1;
+    ProfCall prof_call(plan, stream);
     if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
     if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
     const bool need_skh = variant == PSGDK_GEOM_Q0P5EQ1P5 || variant == PSGDK_GEOM_PRO4P;
@@ -1134,7 +1183,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     hipStream_t st = (hipStream_t)stream;
     const unsigned F = (unsigned)P->dn.size();
     int rc;
-    if ((rc = nlb_check_error(P))) return rc;
+    if (do_a && (rc = nlb_check_error(P))) return rc;
     if (noise) {
         HIPCHK(hipMemcpyAsync(P->d_noise_g, noise->g_noise, P->n_tensors * sizeof(void*), hipMemcpyHostToDevice, st));
         if (F) {
@@ -1153,74 +1202,106 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
-    if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
-    P->zero_clean = false;
-    P->bal_clean = true;
-    if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
-        std::vector<uint8_t> all(P->n_tensors, 1);
-        if ((rc = run_balance(P, all.data(), st))) return rc;
-        P->p_valid = false;
-    }
-    // damped input X (psgd.py:402-403), unless psgdk_accumulate already produced exactly this X
-    const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
-                         P->x_offset == offset && P->x_explicit == (noise != nullptr);
-    P->x_valid = false;
-    if (!x_ready)
-        DISPATCH_T(P, hipLaunchKernelGGL(make_x_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
-                                         P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
-    // Pg = (kron Q^T Q) X and the mode Grams (psgd.py:403-405)
-    if ((rc = ensure_P(P, st))) return rc;
-    launch_stage(P, P->g_upd_a, st);
-    launch_stage(P, P->g_upd_b, st);
-    if (P->n_tiles_diag)
-        DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
-                                         P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off), P->p_mode() ? 1 : 0));
-    // N-D tensors: Pg mode by mode, then every mode's Gram (dense -> term1 + its row stats; diagonal -> the sum vector)
-    for (const GenDesc& g : P->gd) {
-        const TensorDesc& D = P->td[g.tensor];
-        DISPATCH_T(P, {
-            const T* Pg = gen_apply_chain<T>(P, g, (const T*)(P->work + D.x_off), (T*)nullptr, (float*)nullptr, st);
-            int64_t A = 1;
-            for (int i = 0; i < g.ndim; ++i) {
-                const int s_ = g.dims[i];
-                const int64_t B = D.numel / (A * s_);
-                if (g.fkind[i] == PSGDK_DENSE) {
-                    const DenseDesc& Fd = P->dn[g.fidx[i]];
-                    T* T1 = (T*)(P->work + Fd.t1_off);
-                    // chunks of the (a, b) range: enough workgroups to pull the tensor out of HBM at speed (about a thousand), at
-                    // least 4096 terms each, and Z s^2 partial sums within the factor's scratch
-                    const int64_t blocks = (int64_t)s_ * ((s_ + 63) / 64);
-                    const int64_t AB = D.numel / s_;
-                    int64_t Z = std::max<int64_t>(1, std::min<int64_t>(256, 1024 / blocks));
-                    Z = std::min<int64_t>(Z, std::max<int64_t>(1, AB / 4096));
-                    Z = std::min<int64_t>(Z, std::max<int64_t>(1, (int64_t)PSGDK_GEN_GPART / ((int64_t)s_ * s_)));
-                    if (Z > 1 && Fd.gpart_off) {
-                        float* gp = (float*)(P->work + Fd.gpart_off);
-                        hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64, (unsigned)Z), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1,
-                                           Fd.dp, (float*)nullptr, gp);
-                        hipLaunchKernelGGL(gen_gram_finish_kernel<T>, dim3(s_), dim3(256), 0, st, (const float*)gp, (int)Z, s_, T1, Fd.dp);
-                    } else
-                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1, Fd.dp,
-                                       (float*)nullptr, (float*)nullptr);
-                    hipLaunchKernelGGL(gen_rowstats_kernel<T>, dim3(s_), dim3(256), 0, st, (const T*)T1, s_, Fd.dp,
-                                       (float*)(P->work + Fd.rowss_off), (float*)(P->work + Fd.sc_off) + DS_NF);
-                } else {
-                    hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, 1), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 0, (T*)nullptr, 0,
-                                       (float*)(P->work + P->dd[g.fidx[i]].sum_off));
+    if (do_a) {
+        if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+        P->zero_clean = false;
+        P->bal_clean = true;
+        if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
+            std::vector<uint8_t> all(P->n_tensors, 1);
+            if ((rc = run_balance(P, all.data(), st))) return rc;
+            P->p_valid = false;
+        }
+        // damped input X (psgd.py:402-403), unless psgdk_accumulate already produced exactly this X
+        const bool x_ready = P->x_valid && P->x_source == source && P->x_damping == damping && P->x_seed == seed &&
+                             P->x_offset == offset && P->x_explicit == (noise != nullptr);
+        P->x_valid = false;
+        if (!x_ready)
+            DISPATCH_T(P, hipLaunchKernelGGL(make_x_kernel<T>, dim3(P->n_tiles_all), dim3(256), 0, st, P->d_td, P->d_tiles_all, ng,
+                                             P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
+        // Pg = (kron Q^T Q) X and the mode Grams (psgd.py:403-405)
+        if ((rc = ensure_P(P, st))) return rc;
+        launch_stage(P, P->g_upd_a, st);
+        launch_stage(P, P->g_upd_b, st);
+        if (P->n_tiles_diag)
+            DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
+                                             P->d_tiles_diag, P->state, P->work, 0, 0, (float*)(P->work + P->hsumsq_off), P->p_mode() ? 1 : 0));
+        // N-D tensors: Pg mode by mode, then every mode's Gram (dense -> term1 + its row stats; diagonal -> the sum vector)
+        for (const GenDesc& g : P->gd) {
+            const TensorDesc& D = P->td[g.tensor];
+            DISPATCH_T(P, {
+                const T* Pg = gen_apply_chain<T>(P, g, (const T*)(P->work + D.x_off), (T*)nullptr, (float*)nullptr, st);
+                int64_t A = 1;
+                for (int i = 0; i < g.ndim; ++i) {
+                    const int s_ = g.dims[i];
+                    const int64_t B = D.numel / (A * s_);
+                    if (g.fkind[i] == PSGDK_DENSE) {
+                        const DenseDesc& Fd = P->dn[g.fidx[i]];
+                        T* T1 = (T*)(P->work + Fd.t1_off);
+                        // chunks of the (a, b) range: enough workgroups to pull the tensor out of HBM at speed (about a thousand), at
+                        // least 4096 terms each, and Z s^2 partial sums within the factor's scratch
+                        const int64_t blocks = (int64_t)s_ * ((s_ + 63) / 64);
+                        const int64_t AB = D.numel / s_;
+                        int64_t Z = std::max<int64_t>(1, std::min<int64_t>(256, 1024 / blocks));
+                        Z = std::min<int64_t>(Z, std::max<int64_t>(1, AB / 4096));
+                        Z = std::min<int64_t>(Z, std::max<int64_t>(1, (int64_t)PSGDK_GEN_GPART / ((int64_t)s_ * s_)));
+                        if (Z > 1 && Fd.gpart_off) {
+                            float* gp = (float*)(P->work + Fd.gpart_off);
+                            hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64, (unsigned)Z), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1,
+                                               Fd.dp, (float*)nullptr, gp);
+                            hipLaunchKernelGGL(gen_gram_finish_kernel<T>, dim3(s_), dim3(256), 0, st, (const float*)gp, (int)Z, s_, T1, Fd.dp);
+                        } else
+                        hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, (s_ + 63) / 64), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 1, T1, Fd.dp,
+                                           (float*)nullptr, (float*)nullptr);
+                        hipLaunchKernelGGL(gen_rowstats_kernel<T>, dim3(s_), dim3(256), 0, st, (const T*)T1, s_, Fd.dp,
+                                           (float*)(P->work + Fd.rowss_off), (float*)(P->work + Fd.sc_off) + DS_NF);
+                    } else {
+                        hipLaunchKernelGGL(gen_gram_kernel<T>, dim3(s_, 1), dim3(256), 0, st, Pg, (int)A, s_, (int)B, 0, (T*)nullptr, 0,
+                                           (float*)(P->work + P->dd[g.fidx[i]].sum_off));
+                    }
+                    A *= s_;
                 }
-                A *= s_;
+            });
+        }
+        if (F) {
+            launch_stage(P, P->g_gram, st);
+            for (int f : P->split_dense) {
+                const DenseDesc& D = P->dn[f];
+                const GemmProblem& g = P->g_gram.probs[P->gram_prob[f]];
+                const int nks = (g.K + g.kchunk - 1) / g.kchunk;
+                const unsigned nblk = (unsigned)((D.dp / 64) * (D.dp / 64 + 1) / 2);
+                const int sh = P->shard_of(D.tensor);
+                if (sh >= 0)      // a row shard's Gram is PARTIAL: the fp32 sum of its slabs goes into this member's exchange record
+                    hipLaunchKernelGGL(slab_sum_upper_kernel, dim3(nblk), dim3(256), 0, st, (const float*)g.slab, nks, D.dp,
+                                       (float*)(xchg + (size_t)P->shard_member * P->xchg_record_bytes + P->shards[sh].rec_off));
+                else
+                    DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3(nblk), dim3(256), 0, st,
+                                                     (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, g.row_sumsq, g.diag_max, D.d, (size_t)D.dp * D.dp));
             }
-        });
+        }
+        if (phase == 0) {
+            // ... and its own maximum of the diagonal factor's term1 (the rest of that factor's update is row-local)
+            DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state, P->work,
+                                             (float*)(P->work + P->diag_mu_off), 2, lr_eff, betaL, 0, xchg, (unsigned long long)P->xchg_record_bytes,
+                                             P->shard_members, P->shard_member));
+            HIPCHK(hipGetLastError());
+            P->update_open = true;
+            return PSGDK_OK;
+        }
     }
-    if (F) {
-        launch_stage(P, P->g_gram, st);
-        for (int f : P->split_dense) {
+    if (phase == 1) {
+        // the shards' mode Grams from ALL members' partials (summed in member order: every member forms the same term1), rounded once,
+        // with the row statistics the unsplit epilogue would have produced
+        P->update_open = false;
+        for (const auto& sh : P->shards) {
+            const int f = P->td[sh.tensor].col_dense;
             const DenseDesc& D = P->dn[f];
             const GemmProblem& g = P->g_gram.probs[P->gram_prob[f]];
-            const int nks = (g.K + g.kchunk - 1) / g.kchunk;
             DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((unsigned)((D.dp / 64) * (D.dp / 64 + 1) / 2)), dim3(256), 0, st,
-                                             (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, g.row_sumsq, g.diag_max, D.d));
+                                             (const float*)(xchg + sh.rec_off), (T*)g.C, D.dp, D.dp, P->shard_members, 1.0f, g.row_sumsq, g.diag_max,
+                                             D.d, P->xchg_record_bytes / 4));
         }
+    }
+    if (F) {
         const dim3 grows((unsigned)(P->max_dp / 64), F);
         // ell = ||term1||_lb + numel/d, L, mu (psgd.py:413-414 -> 46-68); row stats of term1 came with the Gram
         if (qep) {
@@ -1239,11 +1320,10 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
             // Q' = Q - mu (term1 Q - c Q) (psgd.py:415)
             launch_stage(P, P->g_qupd, st);
             // procrustes_step2 (psgd.py:416 -> 101-124); its line search and AXPY are fused into the R RQ product
-            if (P->chain_t()) {
+            {
                 const unsigned nb = (unsigned)(P->max_dp / 64);
                 DISPATCH_T(P, hipLaunchKernelGGL(rsub_t_kernel<T>, dim3(nb * (nb + 1) / 2, F), dim3(256), 0, st, P->d_dn, P->work));
             }
-            else DISPATCH_T(P, hipLaunchKernelGGL(rsub_kernel<T>, grows, dim3(256), 0, st, P->d_dn, P->work));
             if ((rc = run_nlb(P, 1, nskh, seed, offset, lr, betaL, 1, -1, st))) return rc;
             launch_stage(P, P->g_rq, st);
             launch_stage(P, P->g_rrq, st);
@@ -1284,7 +1364,8 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     {
         float* mu = (float*)(P->work + P->diag_mu_off);
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
-                                         P->work, mu, 0, lr_eff, betaL, quadlike ? 1 : 0));
+                                         P->work, mu, 0, lr_eff, betaL, quadlike ? 1 : 0, xchg, (unsigned long long)P->xchg_record_bytes,
+                                         P->shard_members, P->shard_member));
         const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
         DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
                                          P->state, P->work, mu, 1, lr_eff, betaL, quadlike ? 1 : 0));
@@ -1298,6 +1379,41 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
 int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                                    uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
     return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream);
+}
+int psgdk_update_precond_begin(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
+                               uint64_t offset, void* exchange, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, nullptr, stream, 0, exchange);
+}
+int psgdk_update_precond_finish(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
+                                uint64_t offset, const void* exchange, const uint8_t* balance_mask, void* stream) {
+    return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream, 1,
+                                (void*)exchange);
+}
+// balance_kron_precond (psgd.py:266-275) of ROW SHARDS in two calls: phase 0 leaves max |q| of the shard's two factors in the plan's
+// balancing slots (PSGDK_INFO_BALNORM_OFFSET: 2 floats per flagged shard, in tensor order; the caller takes the maximum over the
+// members), phase 1 rescales with what it finds there.  The same mask in both calls; only row shards may be flagged.
+int psgdk_balance_phase(psgdk_plan* plan, const uint8_t* mask, int phase, void* stream) {
+    if (!plan || !mask || (phase != 0 && phase != 1)) return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int>& which = P->h_balance;
+    which.clear();
+    for (int t = 0; t < P->n_tensors; ++t)
+        if (mask[t]) { if (P->shard_of(t) < 0) return PSGDK_ERR_INVALID; which.push_back(t); }
+    if (which.empty()) return PSGDK_OK;
+    if (which.size() > 15) return PSGDK_ERR_UNSUPPORTED;
+    BalanceList inl{};
+    inl.n = (int)which.size();
+    for (size_t i = 0; i < which.size(); ++i) inl.t[i] = which[i];
+    float* balnorm = (float*)(P->work + P->balnorm_off);
+    if (phase == 0) HIPCHK(hipMemsetAsync(balnorm, 0, 2 * which.size() * sizeof(float), st));
+    P->bal_clean = false;
+    DISPATCH_T(P, hipLaunchKernelGGL(balance_kernel<T>, dim3(64, (unsigned)(2 * which.size())), dim3(256), 0, st, P->d_td, P->d_dd, P->d_dn,
+                                     P->d_balance, inl, P->state, balnorm, phase));
+    HIPCHK(hipGetLastError());
+    if (phase == 1) P->p_valid = false;
+    return PSGDK_OK;
 }
 int psgdk_update_precond_qeq(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise,
                              uint64_t seed, uint64_t offset, const uint8_t* balance_mask, void* stream) {
@@ -1320,18 +1436,9 @@ int psgdk_update_precond_qep(psgdk_plan* plan, int source, float lr, float betaL
     return update_whiten_family(plan, PSGDK_GEOM_QEP, source, lr, betaL, damping, noise, seed, offset, nullptr, stream);
 }
 
-// the bf16 solve (panel resident in LDS, updates on the bf16 matrix cores); PSGDK_TRSM=f32 keeps the fp32-core kernel (A/B runs)
-static bool trsm_f32_cores() {
-    static const bool v = [] { const char* e = std::getenv("PSGDK_TRSM"); return e && std::string(e) == "f32"; }();
-    return v;
-}
-// shape of the bf16 solve: 0 = 32-row panels, two workgroups per CU; 1 = 64-row panels.  PSGDK_TRSM_SHAPE overrides the default (A/B).
+// shape of the bf16 solve: 0 = 32-row panels, two workgroups per CU; 1 = 64-row panels (test hook: psgdk_test_trsm_bench)
 #define TRSM_SHAPE_DEFAULT 0
-static int trsm_shape() {
-    static const int v = [] { const char* e = std::getenv("PSGDK_TRSM_SHAPE"); const int x = e ? std::atoi(e) : TRSM_SHAPE_DEFAULT;
-                              return (x >= 0 && x <= 1) ? x : TRSM_SHAPE_DEFAULT; }();
-    return v;
-}
+static int trsm_shape() { return TRSM_SHAPE_DEFAULT; }
 static int launch_trsm_bf16(const TrsmJob* jobs, const TrsmTile* tiles, unsigned n_tiles, int max_dp, hipStream_t st, int dbg = 0,
                             int shape = -1) {
     if (shape < 0) shape = trsm_shape();
@@ -1355,6 +1462,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
                             const uint8_t* balance_mask, void* stream) {
     if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
     if (!plan->state || plan->geometry != PSGDK_GEOM_EQ) return PSGDK_ERR_STATE;
+    ProfCall prof_call(plan, stream);
     if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
     if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
     if (noise && (!noise->g_noise || (!plan->dn.empty() && !noise->spd_noise))) return PSGDK_ERR_INVALID;
@@ -1392,7 +1500,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
         DISPATCH_T(P, hipLaunchKernelGGL(eq_uinv_kernel<T>, dim3((unsigned)(P->max_dp / 64), P->n_uinv), dim3(64), 0, st, P->d_uinv));
     for (int k = 0; k < 2; ++k)
         if (P->n_trsm_tiles[k]) {
-            if (P->dtype == PSGDK_BF16 && P->max_dp <= EQ_TRSM_BF16_MAX_DP && !trsm_f32_cores()) {
+            if (P->dtype == PSGDK_BF16 && P->max_dp <= EQ_TRSM_BF16_MAX_DP) {
                 const int rc = launch_trsm_bf16(P->d_trsm[k], P->d_trsm_tiles[k], P->n_trsm_tiles[k], P->max_dp, st);
                 if (rc) return rc;
             } else
@@ -1441,7 +1549,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
                 const DenseDesc& D = P->dn[f];
                 const int nks = (g.K + g.kchunk - 1) / g.kchunk;
                 DISPATCH_T(P, hipLaunchKernelGGL(splitk_reduce_sym_kernel<T>, dim3((unsigned)((D.dp / 64) * (D.dp / 64 + 1) / 2)), dim3(256), 0,
-                                                 st, (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, (float*)nullptr, (float*)nullptr, D.d));
+                                                 st, (const float*)g.slab, (T*)g.C, D.dp, D.dp, nks, 1.0f, (float*)nullptr, (float*)nullptr, D.d, (size_t)D.dp * D.dp));
             }
         }
         const dim3 grows((unsigned)(P->max_dp / 64), F);
@@ -1471,6 +1579,7 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     if (!plan || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
     if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+    ProfCall prof_call(plan, stream);
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -1500,6 +1609,7 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
     if (!plan->state) return PSGDK_ERR_STATE;
     if (!(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
     for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
+    ProfCall prof_call(plan, stream);
     hipStream_t st = (hipStream_t)stream;
     int rcp;
     void** d_params = nullptr;
@@ -1605,6 +1715,7 @@ int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype
     if (!plan || !outs || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
     for (int t = 0; t < plan->n_tensors; ++t) if (!outs[t]) return PSGDK_ERR_INVALID;
+    ProfCall prof_call(plan, stream);
     hipStream_t st = (hipStream_t)stream;
     int rcp;
     void** d_outs = nullptr;
@@ -1623,6 +1734,8 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
         case PSGDK_INFO_NLB_FALLBACKS: *value = plan->nlb_fallbacks; return PSGDK_OK;
         case PSGDK_INFO_DENSE_FACTORS: *value = (int64_t)plan->dn.size(); return PSGDK_OK;
         case PSGDK_INFO_MAX_DENSE_DIM: *value = plan->max_dp; return PSGDK_OK;
+        case PSGDK_INFO_HSUMSQ_OFFSET: *value = (int64_t)plan->hsumsq_off; return PSGDK_OK;
+        case PSGDK_INFO_BALNORM_OFFSET: *value = (int64_t)plan->balnorm_off; return PSGDK_OK;
     }
     return PSGDK_ERR_INVALID;
 }
@@ -1644,6 +1757,20 @@ int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches
     }
     *gemm_ms = tot; *gemm_launches = (int64_t)plan->prof_used;
     if (reset) plan->prof_used = 0;
+    return PSGDK_OK;
+}
+
+int psgdk_profile_read_calls(psgdk_plan* plan, double* call_ms, int64_t* calls, int reset) {
+    if (!plan || !call_ms || !calls) return PSGDK_ERR_INVALID;
+    double tot = 0.0;
+    for (size_t i = 0; i < plan->prof_call_used; ++i) {
+        HIPCHK(hipEventSynchronize(plan->prof_call_ev[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, plan->prof_call_ev[i].first, plan->prof_call_ev[i].second));
+        tot += ms;
+    }
+    *call_ms = tot; *calls = (int64_t)plan->prof_call_used;
+    if (reset) plan->prof_call_used = 0;
     return PSGDK_OK;
 }
 
@@ -1686,6 +1813,31 @@ int psgdk_test_dump_noise(psgdk_plan* plan, uint64_t seed, uint64_t offset, void
                                          (void* const*)P->d_noise_skh, seed, offset, pro_iter));
     }
     HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_test_clock(float* shader_mhz, void* stream) {
+    if (!shader_mhz) return PSGDK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)cus * 2;
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)grid * 2 * sizeof(unsigned long long)));
+    std::vector<unsigned long long> h((size_t)grid * 2);
+    int rc = PSGDK_OK;
+    for (int rep = 0; rep < 2; ++rep)          // (the first launch brings the clocks up)
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(256), 0, st, d, 40000);
+    if (hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) rc = PSGDK_ERR_HIP;
+    (void)hipFree(d);
+    if (rc) return rc;
+    std::vector<double> mhz;
+    for (unsigned b = 0; b < grid; ++b) if (h[2 * b + 1] > 0) mhz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
+    if (mhz.empty()) return PSGDK_ERR_HIP;
+    std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
+    *shader_mhz = (float)mhz[mhz.size() / 2];
     return PSGDK_OK;
 }
 
@@ -1788,8 +1940,11 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
-    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop
-    s.lock = (symmetric & 2048) != 0;
+    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop,
+    s.lock = (symmetric & 2048) != 0;         // bit 24 the 256 x 128 tiling, bit 25 the 64 x 64 K-split one
+    s.mid = (symmetric & (1 << 24)) != 0;
+    s.ksplit = (symmetric & (1 << 25)) != 0;
+    s.late_f2 = (symmetric & (1 << 26)) != 0;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -1816,6 +1971,13 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 2) s.one_per_tile = true;
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
+    if (variant == 13 || variant == 17) { alt.probs = s.probs; alt.mid = true; alt.late_f2 = variant == 17; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
+    if (variant == 14) { alt.probs = s.probs; int rc = finish_stage(alt); if (rc) return rc; s = alt; }     // the 128 x 128 tiling, whatever was bound
+    if (variant == 15 || variant == 16) {     // the middle tiling without its epilogue / without its stores
+        alt.probs = s.probs; alt.mid = true;
+        for (auto& q : alt.probs) q.flags |= (variant == 15 ? GF_DBG_NOEPI : GF_DBG_NOSTORE);
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
     if (variant >= 5 && variant <= 12) {      // same tiling, parts of the epilogue's work stripped / the output discarded
         alt.probs = s.probs; alt.big = s.big;
         for (auto& q : alt.probs) {
@@ -1860,10 +2022,11 @@ int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int 
         s = new Stage();
         GemmProblem P{};
         P.A = A; P.B = B; P.C = C; P.Ct = Ct; P.M = M; P.N = N; P.K = K; P.lda = K; P.ldb = K; P.ldc = N; P.ldct = M; P.alpha = 1.f;
-        P.flags = flags & ~(1024 | 2048 | 16384);
+        P.flags = flags & ~(1024 | 2048 | 16384 | (3 << 24));
         if (!C && Ct) P.flags |= GF_TMAJOR;
         s->probs.push_back(P);
         s->big = (flags & 1024) != 0; s->lock = (flags & 2048) != 0; s->one_per_tile = (flags & 16384) != 0;
+        s->mid = (flags & (1 << 24)) != 0; s->ksplit = (flags & (1 << 25)) != 0;
         int rc = finish_stage(*s);
         if (rc) return rc;
         cache.push_back({Key{A, B, C, Ct, dtype, M, N, K, flags}, s});
@@ -1894,7 +2057,10 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.big = (symmetric & 1024) != 0;
     s.lock = (symmetric & 2048) != 0;
     s.one_per_tile = (symmetric & 16384) != 0;
-    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384);
+    s.mid = (symmetric & (1 << 24)) != 0;
+    s.ksplit = (symmetric & (1 << 25)) != 0;
+    s.late_f2 = (symmetric & (1 << 26)) != 0;
+    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (7 << 24));
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
@@ -2062,13 +2228,6 @@ int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void*
                            if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; LRA_TPR_(tpr_, __VA_ARGS__); }  \
                            else { typedef float T; LRA_TPR_(tpr_, __VA_ARGS__); } } while (0)
 
-// PSGDK_LRA_EARLY_VEC=1 (experiment): the EV instantiations of the row passes (kernels_lra.hiph: N-vector elements requested before the
-// next block's matrix prefetch)
-static bool lra_early_vec() {
-    static const bool v = [] { const char* e = std::getenv("PSGDK_LRA_EARLY_VEC"); return e && e[0] == '1'; }();
-    return v;
-}
-
 // launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of (256 / tpr) x r floats (+ `fixed` bytes of
 // static LDS), and as many workgroups as are resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
 static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm) {
@@ -2113,37 +2272,19 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
             hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
         }
         if constexpr (TPR == 1) {
-            if (lra_early_vec()) hipLaunchKernelGGL((lra_rotate_kernel<T, TPR, true>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
-            else hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
-        } else {      // wider rank classes: the rotation on the fp32 matrix cores (PSGDK_LRA_ROTATE=valu keeps the one-row-per-thread form: A/B)
-            static const bool valu = [] { const char* e = std::getenv("PSGDK_LRA_ROTATE"); return e && e[0] == 'v'; }();
-            if (valu)
-                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
-            else {
-                const int rows_m = LRA_ROWS / TPR;
-                const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
-                hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, vh, N, r, sm);
-            }
+            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
+        } else {      // wider rank classes: the rotation on the fp32 matrix cores
+            const int rows_m = LRA_ROWS / TPR;
+            const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
+            hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, vh, N, r, sm);
         }
         hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        if (lra_early_vec())
-            hipLaunchKernelGGL((lra_pass3_kernel<T, TPR, true>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
-                               Qh, iq, N, r, sm);
-        else
         hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                            Qh, iq, N, r, sm);
         hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        if (lra_early_vec())
-            hipLaunchKernelGGL((lra_pass4_kernel<T, TPR, true>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
-                               (const T*)Qh, (const T*)iq, diff, N, r, sm);
-        else
         hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                            (const T*)Qh, (const T*)iq, diff, N, r, sm);
         hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
-        if (lra_early_vec())
-            hipLaunchKernelGGL((lra_pass5_kernel<T, TPR, true>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
-                               N, r, update_u ? 1 : 0, (const float*)sm);
-        else
         hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                            N, r, update_u ? 1 : 0, (const float*)sm);
     });
@@ -2163,10 +2304,6 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
         HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
         T* y = (T*)(L->work + L->y_off);
         for (int stage = 0; stage < 3; ++stage) {
-            if (lra_early_vec())
-                hipLaunchKernelGGL((lra_apply_kernel<T, TPR, true>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
-                                   (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
-            else
             hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                                (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
         }

@@ -120,9 +120,11 @@ class KronEngine:
 
     def __init__(self, shapes: Sequence[Sequence[int]], device, precond_dtype=torch.bfloat16, max_size=float("inf"),
                  max_skew=1.0, use_momentum=True, init_scale: Optional[float] = 1.0,
-                 tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5"):
+                 tensor_ids: Optional[Sequence[int]] = None, geometry: str = "Q0.5EQ1.5", row_shards=None):
         """shapes: the SQUEEZED shapes of the tensors (wrapped_as_torch_optimizer_for_ddp.py:124).
         tensor_ids: global ids for the Philox noise streams (sharded optimizers pass the un-sharded indices).
+        row_shards: {k: (global_rows, row0, member, members)} -- tensor k is a row block of a larger row-sharded matrix
+        (include/psgdk.h, "row shards"): its update runs as update_begin / exchange / update_finish.
         geometry: the dQ of psgd.init_kron (psgd.py:161): "Q0.5EQ1.5", "EQ" (upper-triangular Q), "QEQ", "QUAD", "QEP"."""
         codes = {"Q0.5EQ1.5": L.GEOM_Q0P5EQ1P5, "Q0p5EQ1p5": L.GEOM_Q0P5EQ1P5, "EQ": L.GEOM_EQ, "QEQ": L.GEOM_QEQ,
                  "QUAD": L.GEOM_QUAD, "QEP": L.GEOM_QEP, "QUAD4P": L.GEOM_QUAD4P, "PRO4P": L.GEOM_PRO4P}
@@ -153,6 +155,11 @@ class KronEngine:
             L.check(self.lib.psgdk_plan_set_stream_ids(self._plan, ids), "set_stream_ids")
         if self.geometry != L.GEOM_Q0P5EQ1P5:
             L.check(self.lib.psgdk_plan_set_geometry(self._plan, self.geometry), "set_geometry")
+        self.row_shards = dict(row_shards or {})
+        self.xchg = None
+        for k in sorted(self.row_shards):
+            grow, row0, member, members = self.row_shards[k]
+            L.check(self.lib.psgdk_plan_set_row_shard(self._plan, int(k), int(grow), int(row0), int(member), int(members)), "set_row_shard")
         sb, wb = C.c_size_t(), C.c_size_t()
         L.check(self.lib.psgdk_plan_arena_bytes(self._plan, C.byref(sb), C.byref(wb)), "arena_bytes")
         with torch.cuda.device(self.device):
@@ -160,6 +167,21 @@ class KronEngine:
             self.work_arena = torch.zeros(wb.value, dtype=torch.uint8, device=self.device)
             L.check(self.lib.psgdk_plan_bind(self._plan, self.state_arena.data_ptr(), self.work_arena.data_ptr()), "bind")
         self._build_views()
+        if self.row_shards:
+            rb = C.c_size_t()
+            L.check(self.lib.psgdk_plan_exchange_bytes(self._plan, C.byref(rb)), "exchange_bytes")
+            members = next(iter(self.row_shards.values()))[3]
+            self.member = next(iter(self.row_shards.values()))[2]
+            self.xchg_record_bytes = rb.value
+            with torch.cuda.device(self.device):
+                # `members` records (this member's is written by update_begin; the caller all-gathers the buffer IN PLACE)
+                self.xchg = torch.zeros(members * rb.value, dtype=torch.uint8, device=self.device)
+            hoff, boff = C.c_int64(), C.c_int64()
+            L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_HSUMSQ_OFFSET, C.byref(hoff)), "plan_info")
+            L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_BALNORM_OFFSET, C.byref(boff)), "plan_info")
+            # device views the caller reduces over the members: the shards' sums of h^2 (one float each), the balancing slots
+            self.hsumsq = self.work_arena[hoff.value:hoff.value + 4 * self.n].view(torch.float32)
+            self.balnorm = self.work_arena[boff.value:boff.value + 8 * self.n].view(torch.float32)
         self._keep = []        # host pointer arrays kept alive until the next call
         if init_scale is not None:
             self.init_state(init_scale)
@@ -296,6 +318,56 @@ class KronEngine:
                                         int(offset), bm, self._stream()))
         self._keep_noise = keep
 
+    def _noise_arg(self, noise):
+        if noise is None:
+            return None, []
+        g_noise, spd, skh = noise
+        gl = [x.to(self.dtype).contiguous() for x in g_noise]
+        keep = []
+        ga = L.ptr_array(gl)
+        sa = (C.c_void_p * (L.MAX_DIMS * self.n))()
+        ka = (C.c_void_p * (L.MAX_DIMS * self.n))()
+        for (t, i), x in spd.items():
+            x = x.to(self.dtype).contiguous(); keep.append(x); sa[t * L.MAX_DIMS + i] = x.data_ptr()
+        for (t, i), x in skh.items():
+            x = x.to(self.dtype).contiguous(); keep.append(x); ka[t * L.MAX_DIMS + i] = x.data_ptr()
+        nz = L.Noise(C.cast(ga, C.POINTER(C.c_void_p)), C.cast(sa, C.POINTER(C.c_void_p)), C.cast(ka, C.POINTER(C.c_void_p)))
+        keep += [gl, ga, sa, ka, nz]
+        return C.byref(nz), keep
+
+    @_on_device
+    def update_begin(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0, noise=None):
+        """First half of the update of a plan with row shards (psgd.py:402-405 + this member's partial statistics into its record of
+        self.xchg).  The caller then all-gathers self.xchg in place over the members and calls update_finish with the same arguments."""
+        nz_ptr, keep = self._noise_arg(noise)
+        self._keep_noise = keep
+        self._checked_update(lambda: self.lib.psgdk_update_precond_begin(self._plan, int(source), float(lr), float(betaL), float(damping),
+                                                                         nz_ptr, int(seed), int(offset), self.xchg.data_ptr(), self._stream()))
+
+    @_on_device
+    def update_finish(self, source: int, lr: float, betaL: float, damping: float, seed: int = 0, offset: int = 0, noise=None,
+                      balance_mask: Optional[Sequence[bool]] = None):
+        """Second half (psgd.py:406-418).  Shards flagged in balance_mask are NOT balanced here: balance_shards() does it around the
+        caller's max over the members."""
+        nz_ptr, keep = self._noise_arg(noise)
+        self._keep_noise = keep
+        bm = None
+        if balance_mask is not None:
+            bm = (C.c_uint8 * self.n)(*[1 if b else 0 for b in balance_mask])
+        L.check(self.lib.psgdk_update_precond_finish(self._plan, int(source), float(lr), float(betaL), float(damping), nz_ptr, int(seed),
+                                                     int(offset), self.xchg.data_ptr(), bm, self._stream()), "update_finish")
+
+    @_on_device
+    def balance_shards(self, which: Sequence[int], reduce_max):
+        """balance_kron_precond (psgd.py:266-275) of the row shards `which` (tensor indices of this engine): reduce_max(t) must replace
+        the float32 tensor t by its maximum over the members (an all-reduce) between the two phases."""
+        if not which:
+            return
+        m = (C.c_uint8 * self.n)(*[1 if k in set(which) else 0 for k in range(self.n)])
+        L.check(self.lib.psgdk_balance_phase(self._plan, m, 0, self._stream()), "balance_phase")
+        reduce_max(self.balnorm[:2 * len(which)])
+        L.check(self.lib.psgdk_balance_phase(self._plan, m, 1, self._stream()), "balance_phase")
+
     def _checked_update(self, call):
         """PSGDK_ERR_NLB_TIMEOUT is the library reporting -- once, before enqueueing anything -- that a cooperative norm-bound
         launch of an EARLIER update gave up waiting for a sibling workgroup: the factors concerned skipped that one
@@ -381,4 +453,11 @@ class KronEngine:
     def profile_read(self, reset: bool = True):
         ms, n = C.c_double(), C.c_int64()
         L.check(self.lib.psgdk_profile_read(self._plan, C.byref(ms), C.byref(n), int(reset)), "profile_read")
+        return ms.value, n.value
+
+    @_on_device
+    def profile_read_calls(self, reset: bool = True):
+        """(ms, calls): device time between the first and the last kernel of every hot-path call while profiling was enabled"""
+        ms, n = C.c_double(), C.c_int64()
+        L.check(self.lib.psgdk_profile_read_calls(self._plan, C.byref(ms), C.byref(n), int(reset)), "profile_read_calls")
         return ms.value, n.value

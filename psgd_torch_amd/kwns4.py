@@ -53,12 +53,16 @@ def _unpack(back):
 class _Works:
     """Several asynchronous requests behind the one-request interface of a collective's work handle."""
 
-    def __init__(self, works):
+    def __init__(self, works, after=None):
         self.works = list(works)
+        self.after = after                   # host-staged exchanges: what lands the received bytes on the device
 
     def wait(self):
         for w in self.works:
             w.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
 
 
 class _Bucket:
@@ -470,10 +474,34 @@ class KWNS4(torch.optim.Optimizer):
         assert mine.data_ptr() == flat.data_ptr() + self.rank * seg * flat.element_size() and mine.dtype == flat.dtype
         if self._shard_exchange == "p2p" or b.uneven:
             # exact sizes: every rank sends the used head of its segment to each peer and receives the used heads of theirs (grouped
-            # point-to-point operations: the same code on gloo and RCCL).  Also taken in "all_gather" mode for a chunk whose segments
+            # point-to-point operations).  Also taken in "all_gather" mode for a chunk whose segments
             # are more than a quarter padding -- a collective over equal-size segments would move the padding too.
             used = b.used
             ops = []
+            if flat.is_cuda and torch.distributed.get_backend() != "nccl":
+                # Point-to-point operations are stream-ordered ONLY on RCCL (the collective stream waits for the current stream
+                # when the operation is posted, and work.wait() makes the current stream wait for it).  ProcessGroupGloo's
+                # send / recv take the RAW pointer: on device memory they read the segment through the BAR whenever the socket
+                # is ready -- possibly before psgdk_export_precond_grad has written it (round 3's "ranks diverged") -- and
+                # complete without the device knowing.  So on such a transport the exchange is HOST-STAGED: the used head of the
+                # segment is copied out behind the export on the current stream (the copy returns when the bytes are on the
+                # host), the requests carry host tensors, and wait() copies what arrived into the peers' segments on the current
+                # stream, ahead of the parameter update that reads them.
+                host_out = mine[:used[self.rank]].cpu() if used[self.rank] > 0 else None
+                host_in = {}
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue
+                    if host_out is not None:
+                        ops.append(torch.distributed.P2POp(torch.distributed.isend, host_out, r))
+                    if used[r] > 0:
+                        host_in[r] = torch.empty(used[r], dtype=flat.dtype)
+                        ops.append(torch.distributed.P2POp(torch.distributed.irecv, host_in[r], r))
+
+                def land(flat=flat, seg=seg, host_in=host_in, keep=host_out):
+                    for r, h in host_in.items():
+                        flat[r * seg:r * seg + h.numel()].copy_(h)
+                return _Works(torch.distributed.batch_isend_irecv(ops) if ops else [], after=land)
             for r in range(self.world):
                 if r == self.rank:
                     continue
