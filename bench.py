@@ -36,6 +36,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def lib_sha256():
+    """Hash of the built engine library: stamps the PMC traffic profile (tools/pmc_traffic.py writes it) so that bench.py can tell
+    whether roofline.traffic was measured on the code that is running."""
+    import hashlib
+    path = os.path.join(ROOT, "psgd_torch_amd", "libpsgdk.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def gpt2_shapes(n_layer=12, n_embd=768, vocab=50304, block=1024):
     """misc/gpt2.py: GPTConfig defaults (gpt2.py:215-227), tied wte/lm_head (gpt2.py:252-254)."""
     s = [(vocab, n_embd), (block, n_embd)]
@@ -449,26 +460,37 @@ def main():
     gc.callbacks.append(gc_watch)
 
     fence = sync_all
+    # one event per step boundary on the stream the engine launches on (torch's current stream): no fences, nothing waits on them
+    # until the timed region is over; the per-step device times give the median / min next to the wall-clock mean
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    sampled = []
     fence()
     t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(args.steps):
         on = (not args.no_roofline) and world == 1 and (i % sample == sample - 1)
         if on:
             prof_steps += 1
+        sampled.append(on)
         for e in engines:
             e.profile_enable(on)
         one_step(args.warmup + i)
+        step_ev[i + 1].record()
     host_dt = time.perf_counter() - t0          # host enqueue time (no sync inside): shows whether the host keeps ahead
     fence()
     dt = time.perf_counter() - t0
+    per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    plain = sorted(x for x, on in zip(per_step, sampled) if not on) or sorted(per_step)      # steps without the roofline event pairs
+    step_median, step_min = plain[len(plain) // 2], plain[0]
     gc.callbacks.remove(gc_watch)
     gc_in_timed = {"collections_by_generation": [g["collections"] - b for g, b in zip(gc.get_stats(), gc_before)],
                    "ms_per_step": gc_ms[0] / args.steps}
-    gemm_ms, gemm_launches = 0.0, 0
+    gemm_ms, gemm_launches, call_ms = 0.0, 0, 0.0
     for e in engines:
         ms, n = e.profile_read(reset=True)
         gemm_ms += ms
         gemm_launches += n
+        call_ms += e.profile_read_calls(reset=True)[0]
         e.profile_enable(False)
     if dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -491,6 +513,23 @@ def main():
     if bad:
         raise SystemExit(f"bench.py: non-finite values after the timed region: {bad[:8]}")
     nlb_fallbacks = sum(e.info()["nlb_fallbacks"] for e in engines)
+    # every rank must hold the same parameters after the timed region: a checksum that any differing bit changes, compared over the ranks
+    chk = torch.zeros(2, dtype=torch.float64, device=dev)
+    for k, p_ in enumerate(params):
+        bits = p_.detach().view(torch.int32).to(torch.float64)
+        chk[0] += bits.sum() * (1 + (k % 7))
+        chk[1] += (bits * bits).sum() * 1e-12
+    ranks_agree = True
+    if dist:
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        ranks_agree = bool(torch.equal(lo, hi))
+        # sharded modes: every rank applies the SAME gathered h to its parameters -- any difference is a bug.  Replicas (the reference's
+        # DDP semantics) recompute everything with atomics whose order is free: they agree to rounding, not bit for bit (hence the
+        # reference's resync_every)
+        if not ranks_agree and mode.startswith("sharded"):
+            raise SystemExit(f"bench.py: rank {rank}: the ranks' parameters differ after the timed region (checksum {chk.tolist()})")
 
     # secondary figure: the apply-only step, i.e. the steady state once the update probability is annealed down
     # (momentum + precondition + clip + parameter update; the preconditioner update gated off).  Outside the timed region.
@@ -519,6 +558,11 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        # device time per step from one event per step boundary (steps that do not carry the roofline's event pairs): the wall-clock mean
+        # above moves with the host and the box by 2-4 %, the median / min of the device times do not
+        "ms_per_step_median": step_median, "ms_per_step_min": step_min,
+        # sum over the engine's hot-path calls of (first kernel start -> last kernel end), on the sampled steps: the step without the host
+        "kernel_ms_per_step": (call_ms / prof_steps) if prof_steps else None,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -540,7 +584,8 @@ def main():
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
                    "gc_in_timed_region": gc_in_timed, "apply_only_ms_per_step": apply_only_ms,
                    "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products",
-                   "norm_bound_timeouts": nlb_fallbacks, "state_finite_after_timed_region": True},
+                   "norm_bound_timeouts": nlb_fallbacks, "state_finite_after_timed_region": True,
+                   "ranks_agree_bitwise": ranks_agree, "param_checksum": [float(x) for x in chk.tolist()]},
     }
     if world == 1 and gemm_launches and prof_steps:
         launches_per_step = gemm_launches / prof_steps
@@ -548,12 +593,13 @@ def main():
         achieved = (gemm_flops / launches_per_step) / avg_launch_s / 1e12
         peak = 157.3 if args.fp32 else 2500.0
         # HBM bytes per launch come from a separate rocprofv3 --pmc run (profiles/): counters cannot be read in-process
-        traffic = None
+        traffic = traffic_lib = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if os.path.exists(tpath) and not args.fp32 and args.config == "gpt2-small":
             try:
                 tj = json.load(open(tpath))
                 traffic = (tj.get("gemm_all_tilings") or tj["kernels"]["gemm_nt_kernelIt"])["hbm_bytes_per_launch_corrected"]
+                traffic_lib = tj.get("library_sha256")
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_nt_pipe_kernel <bf16> (all grouped-GEMM launches of the step: the "
@@ -561,6 +607,9 @@ def main():
                            if not args.fp32 else "gemm_nt_kernel<float>",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic,
+                           # the counters were collected on the library whose hash the profile carries; a different library now = stale
+                           "traffic_library_sha256": traffic_lib if traffic is not None else None,
+                           "traffic_stale": (traffic_lib != lib_sha256()) if traffic is not None else None,
                            "traffic_source": ("profiles/pmc_traffic_latest.json: separate rocprofv3 --pmc passes of this command on this "
                                               "code (FETCH_SIZE x 2 + WRITE_SIZE per launch); counters cannot be read in-process")
                            if traffic is not None else None,
@@ -579,6 +628,9 @@ def main():
         pk = (C.c_float * 4)()
         _lib.check(_lib.lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
         del scratch
+        clk = C.c_float()
+        _lib.check(_lib.lib().psgdk_test_clock(C.byref(clk), _lib.current_stream()), "test_clock")
+        out["config"]["shader_clock_mhz_under_mfma_load"] = clk.value
         r = out["roofline"]
         r["peak_measured"] = {"mfma_16x16x32_bf16_tflops": pk[0], "mfma_32x32x16_bf16_tflops": pk[1], "hbm_copy_gbs": pk[2],
                               "hbm_read_gbs": pk[3],

@@ -64,6 +64,7 @@ struct psgdk_plan {
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     PtrTableCache ptrs_a, ptrs_b;                           // device copies of the callers' pointer tables (gradients; parameters / outputs)
     bool zero_clean = false, hsq_clean = false;             // psgdk_accumulate zeroed the update's accumulators / the sums of h^2 in its own pass
+    hipStream_t clean_stream = nullptr;                     // ... on this stream: a consumer on another stream clears them itself
     std::vector<const void*> h_noise_a, h_noise_b;          // staging for explicit-noise pointer tables
     std::vector<void*> h_dump_g;                            // staging of psgdk_test_dump_noise's output table
     std::vector<int> h_balance;
@@ -72,6 +73,7 @@ struct psgdk_plan {
     int* d_balance = nullptr;
     int max_dp = 0;
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
+    bool nlb_small = false;           // ... in its instantiation for plans whose widest factor is <= 128 (one workgroup per factor, 16 columns per wave)
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
     unsigned long long* d_nlb_ts = nullptr;   // psgdk_test_nlb_stamps: NLB_TS_SLOTS words per workgroup (its address sits after the job table)
     // error word of the cooperative kernels: host-mapped pinned memory, so that the host can look at it WITHOUT synchronising
@@ -1043,6 +1045,7 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
     // accumulators (row sums, scalars, arrival counters, balancing norms): one memset launch less for each
     plan->hsq_clean = true;
     plan->zero_clean = damp != nullptr;
+    plan->clean_stream = st;
     if (damp) {
         plan->x_valid = true; plan->x_source = damp->source; plan->x_damping = damp->damping;
         plan->x_seed = damp->seed; plan->x_offset = damp->offset; plan->x_explicit = damp->noise != nullptr;
@@ -1067,8 +1070,13 @@ static int nlb_plan_coop(psgdk_plan* P) {
     std::vector<int> order(P->dn.size());
     for (size_t f = 0; f < order.size(); ++f) order[f] = (int)f;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P->dn[a].dp > P->dn[b].dp; });
+    // plans whose widest factor is <= 128 wide (LeNet5, conv nets): every factor is ONE workgroup's, 16 columns per wave (all eight waves
+    // work on a 128-wide factor) and as many K steps of registers as such a factor has -- the general instantiation loaded 24 K steps
+    // (sized for 768) of which 16 were dead re-reads: 10.5 of the 39 us a bound took on LeNet5's plan (profiles/r04_a)
+    P->nlb_small = P->max_dp <= 128;
+    const int cols_per_wg = P->nlb_small ? 128 : 256;
     for (int f : order) {
-        const int S = (P->dn[f].dp + 255) / 256;
+        const int S = (P->dn[f].dp + cols_per_wg - 1) / cols_per_wg;
         size_t best = 0;
         for (size_t x = 1; x < 8; ++x) if (xcd[x].size() < xcd[best].size()) best = x;
         for (int m = 0; m < S; ++m) xcd[best].push_back(NlbJob{f, m, S, 0});
@@ -1106,6 +1114,7 @@ static int nlb_plan_coop(psgdk_plan* P) {
     // the subspace block (32 rows of the widest factor + 16 bytes each) + eight wave-private publish stages of 32 x (32 T + 16 bytes)
     P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16) + 8 * 32 * (32 * P->esz + 16));
     for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24>, (const void*)nlb_coop_kernel<float, 2, 24>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 4>, (const void*)nlb_coop_kernel<float, 1, 8>,
                           (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
@@ -1115,7 +1124,9 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
                    int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0, bool stamps = false) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
+        if (stamps && P->nlb_small) return PSGDK_ERR_UNSUPPORTED;      // (the instrumented instantiation exists for the general shape only)
         const void* k = stamps ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>)
+                      : P->nlb_small ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
                                : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
@@ -1203,7 +1214,7 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     const void* const* nskh = noise ? (const void* const*)P->d_noise_skh : nullptr;
 
     if (do_a) {
-        if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+        if (!P->zero_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
         P->zero_clean = false;
         P->bal_clean = true;
         if (qep) {      // balancing is not optional for QEP and comes first (psgd.py:346-347)
@@ -1363,12 +1374,14 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
     } else if (!P->dd.empty())
     {
         float* mu = (float*)(P->work + P->diag_mu_off);
-        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
-                                         P->work, mu, 0, lr_eff, betaL, quadlike ? 1 : 0, xchg, (unsigned long long)P->xchg_record_bytes,
-                                         P->shard_members, P->shard_member));
         const unsigned chunks = (unsigned)std::max(1, std::min(16, (P->max_diag_len + 4095) / 4096));
-        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
-                                         P->state, P->work, mu, 1, lr_eff, betaL, quadlike ? 1 : 0));
+        // short diagonals (one workgroup walks a whole factor): both phases in one launch
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3((unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd, P->state,
+                                         P->work, mu, chunks == 1 ? 3 : 0, lr_eff, betaL, quadlike ? 1 : 0, xchg,
+                                         (unsigned long long)P->xchg_record_bytes, P->shard_members, P->shard_member));
+        if (chunks > 1)
+            DISPATCH_T(P, hipLaunchKernelGGL(diag_update_kernel<T>, dim3(chunks, (unsigned)P->dd.size()), dim3(1024), 0, st, P->d_dd,
+                                             P->state, P->work, mu, 1, lr_eff, betaL, quadlike ? 1 : 0));
     }
     if (!qep && (rc = run_balance(P, balance_mask, st))) return rc;
     HIPCHK(hipGetLastError());
@@ -1483,7 +1496,7 @@ int psgdk_update_precond_eq(psgdk_plan* plan, int source, float lr, float betaL,
     }
     const void* const* ng = noise ? (const void* const*)P->d_noise_g : nullptr;
     const void* const* nspd = noise ? (const void* const*)P->d_noise_spd : nullptr;
-    if (!P->zero_clean) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
+    if (!P->zero_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->zero_off, 0, P->zero_bytes, st));
     P->zero_clean = false;
     P->bal_clean = true;
     // V and Hvp = S + (damping + eps|S|) V (psgd.py:334-336), unless psgdk_accumulate already wrote exactly this pair
@@ -1583,7 +1596,7 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     psgdk_plan* P = plan;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (!P->hsq_clean) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
+    if (!P->hsq_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
     P->hsq_clean = false;
     if ((rc = ensure_P(P, st))) return rc;
     launch_stage(P, P->g_app_a[source], st);

@@ -37,17 +37,22 @@ class ShardedGradHookState:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        # owners are ranks of the OPTIMIZER's group (the default group): the hook's group must number the ranks the same way
+        assert self.world == optimizer.world and self.rank == optimizer.rank, "the comm hook's process group must be the optimizer's"
         self.buckets_allreduced = 0
         self.buckets_scattered = 0
         self._owner: Dict[int, int] = {}
+        self._owner_gen = None
 
     def owner_of(self, p) -> int:
-        """Owner rank of parameter p, or -1 while the optimizer has not built the bucket that holds it."""
-        o = self._owner.get(id(p))
-        if o is None:
+        """Owner rank of parameter p; -1 = every rank needs its gradient (a row-split tensor: each rank preconditions a row block);
+        -2 while the optimizer has not built the bucket that holds it.  The map is rebuilt whenever the optimizer's set of buckets
+        changes (a bucket split per parameter, load_state_dict)."""
+        gen = tuple(id(b) for b in self.opt._buckets.values())
+        if gen != self._owner_gen:
             self._owner = {id(q): b.owner[k] for b in self.opt._buckets.values() for k, q in enumerate(b.params)}
-            o = self._owner.get(id(p), -1)
-        return o
+            self._owner_gen = gen
+        return self._owner.get(id(p), -2)
 
 
 def sharded_grad_hook(state: ShardedGradHookState, bucket: dist.GradBucket) -> torch.futures.Future[torch.Tensor]:
@@ -57,7 +62,8 @@ def sharded_grad_hook(state: ShardedGradHookState, bucket: dist.GradBucket) -> t
     grads = bucket.gradients()                    # views of `flat`, in the order of bucket.parameters()
     owners = [state.owner_of(p) for p in bucket.parameters()]
     if any(o < 0 for o in owners) or not state.opt.shard_state:
-        # ownership not decided yet (first iteration) or the optimizer is not sharded: DDP's default behaviour
+        # ownership not decided yet (first iteration), a row-split tensor in the bucket (every rank needs all of its gradient's rows
+        # it owns -- and they are spread over all ranks), or the optimizer is not sharded: DDP's default behaviour
         state.buckets_allreduced += 1
         fut = dist.all_reduce(flat, group=state.group, async_op=True).get_future()
         return fut.then(lambda f: f.value()[0].div_(world))
@@ -72,6 +78,11 @@ def sharded_grad_hook(state: ShardedGradHookState, bucket: dist.GradBucket) -> t
                                   async_op=True)
 
     def finish(_):
+        # (on RCCL this callback runs on a pool stream, not the stream `recv` and `send` were allocated on: tell the caching allocator,
+        #  or it may hand the blocks out again while the sum below is still pending)
+        if recv.is_cuda:
+            recv.record_stream(torch.cuda.current_stream())
+            send.record_stream(torch.cuda.current_stream())
         if mine:
             red = recv.view(world, mine).sum(dim=0).div_(world)           # rank order: the same sum on every transport
             off = 0

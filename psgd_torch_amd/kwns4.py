@@ -13,7 +13,11 @@ What is different, on purpose:
     (RCCL over xGMI); every rank then applies the identical parameter update.  The tensors are worked off in
     `shard_chunks` (default 4) cost-balanced chunks, each with its own exchange buffer: chunk c's asynchronous, in-place
     all-gather travels while chunk c + 1 is preconditioned, and the parameter updates follow chunk by chunk as the
-    gathers land -- on a step this short the fabric, not the arithmetic, is the critical path.
+    gathers land -- on a step this short the fabric, not the arithmetic, is the critical path (DESIGN.md section 6);
+  * (round 4) a DOMINANT matrix whose dim-0 factor is diagonal and whose dim-1 factor is dense (GPT-2's tied embedding) is SPLIT BY ROWS
+    over all ranks (`shard_split_rows`, default on in sharded mode): every rank preconditions one row block with the replicated dense
+    factor, which is fitted to the whole matrix through one small exchange in the middle of the update (the ranks' partial mode Grams,
+    psgd.py:405; include/psgdk.h "row shards").
 """
 from __future__ import annotations
 
@@ -24,7 +28,7 @@ import torch
 
 from . import _lib as L
 from .engine import KronEngine
-from .sharding import assign_owners, chunk_partition, lpt_partition, kron_step_cost
+from .sharding import assign_owners, chunk_partition, lpt_partition, kron_step_cost, row_split_candidates
 
 
 _GEOMETRIES = {"Q0.5EQ1.5", "Q0p5EQ1p5", "EQ", "QEQ", "QUAD", "QEP", "QUAD4P", "PRO4P"}      # psgd.py:161 (init_kron's dQ)
@@ -58,7 +62,10 @@ class _Works:
         self.after = after                   # host-staged exchanges: what lands the received bytes on the device
 
     def wait(self):
-        for w in self.works:
+        # idempotent: a bucket's exchange is waited for in _bucket_finish, and -- with update_preconditioner_first=False on an engine
+        # with the cooperative norm bound -- once before that; a SECOND wait() on a completed gloo receive never returns
+        works, self.works = self.works, []
+        for w in works:
             w.wait()
         if self.after is not None:
             self.after()
@@ -104,6 +111,7 @@ class KWNS4(torch.optim.Optimizer):
             shard_state: bool = False,
             shard_chunks: Optional[int] = None,
             shard_exchange: str = "all_gather",
+            shard_split_rows=True,
             engine_factory=None,
     ):
         # the reference's argument checks, verbatim in meaning (..._ddp.py:45-62)
@@ -176,6 +184,13 @@ class KWNS4(torch.optim.Optimizer):
         self._pos_cache = {}
         self._owners = {}            # chunked buckets: bucket key -> {position of the parameter in its group: owner rank}
         self._legacy_owners = False  # a checkpoint of rounds 1-3 (owners chosen chunk by chunk) was loaded: keep that rule
+        # row-split tensors: (bucket key without chunk / split suffix) -> {position in the group: [(row0, row1)] * world}; decided when the
+        # key is first seen (cost model, deterministic on every rank), part of the checkpoint
+        # shard_split_rows: True = tensors that cost more than half a rank's fair share of their group; a float = that fraction (0.0:
+        # every tensor of the right structure); False = none
+        self._split_rows = shard_split_rows is not False and self.shard_state and self.dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5")
+        self._split_rows_threshold = 0.5 if shard_split_rows is True else float(shard_split_rows or 0.0)
+        self._rowsplit = {}
 
     # what the engine sees of a parameter: the tensors themselves here; the DTensor shell (kwns4_dtensor.py) hands over
     # the local shards (wrapped_as_torch_optimizer_for_dtensor.py:123,156)
@@ -215,8 +230,9 @@ class KWNS4(torch.optim.Optimizer):
         rebuilt when the group's parameter list changes (add_param_group, a list edited in place)."""
         c = self._pos_cache.get(gi)
         params = group["params"]
-        if c is None or c[0] is not params or c[1] != len(params):
-            c = self._pos_cache[gi] = (params, len(params), {id(p): k for k, p in enumerate(params)})
+        ids = tuple(map(id, params))          # (a parameter replaced in place keeps the list's identity and length: compare the ids)
+        if c is None or c[0] is not params or c[1] != ids:
+            c = self._pos_cache[gi] = (params, ids, {i: k for k, i in enumerate(ids)})
         return c[2]
 
     # --------------------------------------------------------------------------------------------------------------
@@ -229,19 +245,29 @@ class KWNS4(torch.optim.Optimizer):
         launch granularity for that group."""
         p0, g0 = self._data_of(plist[0]), self._grad_of(plist[0])
         key = (gi, p0.dtype, g0.dtype, p0.device)
+        pos = self._pos(gi, group)
+        if self.shard_state and key not in self._rowsplit:
+            # which tensors are split by rows over all ranks: decided ONCE per key from the cost model (the same on every rank)
+            self._rowsplit[key] = {}
+            if self._split_rows and not self._legacy_owners and not getattr(self, "_rowsplit_frozen", False):
+                shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]
+                costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
+                cand = row_split_candidates(shapes, costs, self.world, group["preconditioner_max_size"], group["preconditioner_max_skew"],
+                                            threshold=self._split_rows_threshold)
+                self._rowsplit[key] = {pos[id(plist[i])]: [tuple(b) for b in blocks] for i, blocks in cand.items()}
         if self._shard_chunks <= 1:
             return self._buckets_for_key(gi, group, plist, key)
-        pos = self._pos(gi, group)
         ch = self._chunks.get(key)           # {position in the group: chunk}; part of the checkpoint
         if ch is None:
             shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]
-            costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
+            costs = self._unit_costs(gi, group, key, plist, shapes)
             part = chunk_partition(costs, self._shard_chunks, self.world)         # deterministic: the same on every rank
             ch = self._chunks[key] = {pos[id(p)]: c for p, c in zip(plist, part)}
             if not self._legacy_owners:
                 # owners over ALL chunks at once (every rank's total, not each chunk's slowest rank, bounds the arithmetic: the
-                # exchanges are asynchronous); part of the checkpoint like the chunk map
-                own = assign_owners(costs, part, self._shard_chunks, self.world)
+                # exchanges are asynchronous); part of the checkpoint like the chunk map.  Row-split tensors: -1 (every rank a block)
+                rs = self._rowsplit.get(key, {})
+                own = assign_owners(costs, part, self._shard_chunks, self.world, split=[i for i, p in enumerate(plist) if pos[id(p)] in rs])
                 self._owners[key] = {pos[id(p)]: r for p, r in zip(plist, own)}
         own = self._owners.get(key)
         out = []
@@ -249,6 +275,17 @@ class KWNS4(torch.optim.Optimizer):
             sub = [p for p in plist if ch.get(pos[id(p)], 0) == c]     # (a parameter first seen later joins chunk 0, which then splits)
             if sub:
                 out += self._buckets_for_key(gi, group, sub, key + ("c", c), own)
+        return out
+
+    def _unit_costs(self, gi, group, key, plist, shapes):
+        """Per-rank cost of every tensor: its step cost -- ONE row block's for a row-split tensor."""
+        pos = self._pos(gi, group)
+        rs = self._rowsplit.get(key[:4], {})
+        ms, sk = group["preconditioner_max_size"], group["preconditioner_max_skew"]
+        out = []
+        for p, s in zip(plist, shapes):
+            blocks = rs.get(pos[id(p)])
+            out.append(kron_step_cost(s, ms, sk) if blocks is None else max(kron_step_cost((b[1] - b[0], s[1]), ms, sk) for b in blocks))
         return out
 
     def _buckets_for_key(self, gi: int, group, plist: List[torch.Tensor], key, own=None):
@@ -326,20 +363,29 @@ class KWNS4(torch.optim.Optimizer):
         if shapes is None:
             shapes = [tuple(self._grad_of(p).squeeze().shape) for p in plist]        # ..._ddp.py:124
         b.pd = pd
+        # row blocks of the row-split tensors of this bucket: {index in plist: [(row0, row1)] * world}; this rank works on block `rank`
+        rs = self._rowsplit.get(key[:4], {}) if self.shard_state else {}
+        b.blocks = {i: rs[pos[id(p)]] for i, p in enumerate(plist) if pos[id(p)] in rs}
         if self.shard_state:
             if owner is None:
-                costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
-                owner = lpt_partition(costs, self.world)
+                costs = self._unit_costs(gi, group, key, plist, shapes)
+                owner = assign_owners(costs, None, 1, self.world, split=list(b.blocks))
+            owner = [-1 if i in b.blocks else o for i, o in enumerate(owner)]
             b.owner = owner
-            b.owned = [i for i, o in enumerate(owner) if o == self.rank]
+            b.owned = [i for i, o in enumerate(owner) if o == self.rank or o == -1]
         else:
             b.owner = [self.rank] * len(plist)
             b.owned = list(range(len(plist)))
         b.shapes = shapes
+        # what this rank's engine holds of tensor i: the tensor, or its row block
+        b.rows = {i: b.blocks[i][self.rank] for i in b.blocks}
+        eshape = {i: ((b.rows[i][1] - b.rows[i][0], shapes[i][1]) if i in b.rows else shapes[i]) for i in b.owned}
         if b.owned:
             p4 = self.dQ in ("QUAD4P", "PRO4P")          # the factors are P itself: init_kron squares the scale (psgd.py:186-187)
             geom = {} if self.dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5") else {"geometry": self.dQ}
-            b.engine = self._engine_factory([shapes[i] for i in b.owned], p0.device, precond_dtype=pd,
+            if b.blocks:
+                geom["row_shards"] = {k: (shapes[i][0], b.rows[i][0], self.rank, self.world) for k, i in enumerate(b.owned) if i in b.rows}
+            b.engine = self._engine_factory([eshape[i] for i in b.owned], p0.device, precond_dtype=pd,
                                             max_size=group["preconditioner_max_size"],
                                             max_skew=group["preconditioner_max_skew"],
                                             use_momentum=group["momentum"] > 0.0,
@@ -355,9 +401,20 @@ class KWNS4(torch.optim.Optimizer):
         if self.shard_state:
             # flat exchange buffer: equal-size (padded) segment per rank, in owner order; every tensor starts at a multiple of 8
             # elements so that the fused parameter update reads it with 16-byte accesses
-            numels = [math.prod(s) if len(s) else 1 for s in shapes]
+            # pieces of the exchange: (tensor, row0, row1, owner) -- a whole tensor from its owner, or one row block from every rank
+            pieces = []
+            for i, s in enumerate(shapes):
+                if i in b.blocks:
+                    pieces += [(i, r0, r1, r) for r, (r0, r1) in enumerate(b.blocks[i])]
+                else:
+                    pieces.append((i, None, None, owner[i]))
+
+            def pnumel(pc):
+                i, r0, r1, _ = pc
+                return (r1 - r0) * shapes[i][1] if r0 is not None else (math.prod(shapes[i]) if len(shapes[i]) else 1)
+            numels = [pnumel(pc) for pc in pieces]
             pad8 = [(n + 7) // 8 * 8 for n in numels]
-            per_rank = [sum(pad8[i] for i in range(len(plist)) if owner[i] == r) for r in range(self.world)]
+            per_rank = [sum(pad8[k] for k, pc in enumerate(pieces) if pc[3] == r) for r in range(self.world)]
             seg = max(per_rank + [8])
             b.seg = seg
             # what each rank really has to send (elements at the head of its segment).  A dominant tensor (GPT-2's wte: 38.6 M of the
@@ -367,13 +424,15 @@ class KWNS4(torch.optim.Optimizer):
             b.uneven = seg * self.world > 1.25 * sum(per_rank)
             b.flat = torch.zeros(self.world * seg, dtype=pd, device=p0.device)
             offs = [r * seg for r in range(self.world)]
-            b.h_views, h_offsets = [], []
-            for i, s in enumerate(shapes):
-                r = owner[i]
-                b.h_views.append(b.flat[offs[r]:offs[r] + numels[i]].view(s))
+            b.h_views, h_offsets = [None] * len(shapes), []
+            for k, (i, r0, r1, r) in enumerate(pieces):
+                view = b.flat[offs[r]:offs[r] + numels[k]].view(shapes[i] if r0 is None else (r1 - r0, shapes[i][1]))
+                if r0 is None or r == self.rank:
+                    b.h_views[i] = view                  # where THIS rank's engine exports tensor i (its row block of a split one)
                 h_offsets.append(offs[r])
-                offs[r] += pad8[i]
-            # p <- p (1 - wd lr) - lr h for all tensors from the gathered buffer: one launch (engine-provided)
+                offs[r] += pad8[k]
+            b.pieces = pieces
+            # p <- p (1 - wd lr) - lr h for all pieces from the gathered buffer: one launch (engine-provided)
             b.flat_apply = self._engine_factory.FlatApply(numels, h_offsets, p0.device)
         self._buckets[key] = b
         pending = getattr(self, "_pending_restore", None)
@@ -402,9 +461,27 @@ class KWNS4(torch.optim.Optimizer):
             items = []
             for plist in by_dtype.values():
                 for b, sub in self._buckets_for(gi, group, plist):
-                    work = self._bucket_compute(b, group, sub, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp)
-                    items.append((b, sub, work))
-            for b, sub, work in items:
+                    items.append([b, sub, self._bucket_compute(b, group, sub, updateP_first, updateP_last, momentum, max_avg_amp,
+                                                               max_element_amp), None])
+            # _bucket_compute is a generator: a bucket with row-split tensors yields once, right after it has posted the exchange of
+            # its partial mode Grams in the middle of its preconditioner update -- those buckets go FIRST up to that point, every other
+            # bucket then runs while the records travel, and the row-split buckets finish last (their update needs the gathered
+            # records).  Buckets without row-split tensors never yield.
+            def run(it):
+                try:
+                    next(it[2])
+                    return False
+                except StopIteration as e:
+                    it[3] = e.value
+                    return True
+            paused = [it for it in items if it[0].blocks and not run(it)]
+            for it in items:
+                if not it[0].blocks:
+                    run(it)
+            for it in paused:
+                while not run(it):
+                    pass
+            for b, sub, _, work in items:
                 self._bucket_finish(b, group, sub, work)
         self._global_step += 1
         left = getattr(self, "_pending_restore", None)
@@ -418,6 +495,8 @@ class KWNS4(torch.optim.Optimizer):
                           "so far, or a checkpoint taken from a different parameter list / sharding)", RuntimeWarning, stacklevel=2)
 
     def _bucket_compute(self, b, group, plist, updateP_first, updateP_last, momentum, max_avg_amp, max_element_amp):
+        """A GENERATOR (see step()): runs the bucket's arithmetic and returns the handle of its exchange (sharded mode) through
+        StopIteration; yields once in the middle of the update of a bucket with row-split tensors."""
         wd, lr = group["weight_decay"], group["lr_params"]
         decoupled = group["decoupled_weight_decay"]
         t = b.step
@@ -425,11 +504,39 @@ class KWNS4(torch.optim.Optimizer):
         src_w = L.SRC_GRAD if group["whiten_grad"] else L.SRC_EMA                     # ..._ddp.py:145
         src_p = L.SRC_GRAD if momentum == 0.0 else L.SRC_EMA                          # ..._ddp.py:150
         eng = b.engine
+
+        def mine(i, x):      # what this rank's engine sees of tensor i: the tensor, or its row block (rows are contiguous)
+            return x if i not in b.rows else x[b.rows[i][0]:b.rows[i][1]]
+        shard_k = [k for k, i in enumerate(b.owned) if i in b.rows]      # engine indices of the row blocks
+
+        def update(offset):
+            """The preconditioner update of this bucket's engine; with row blocks it is cut in two around the exchange of the ranks'
+            partial statistics (include/psgdk.h, "row shards"), and the generator yields while that exchange travels."""
+            draws = self._update_draws(b, plist)
+            if not shard_k:
+                eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed, offset=offset, **draws)
+                return
+            noise = draws.get("noise")
+            if noise is not None:      # replayed draws come per TENSOR: this rank's rows of the damping noise
+                g_noise, spd, skh = noise
+                noise = ([mine(b.owned[k], g) if k in shard_k else g for k, g in enumerate(g_noise)], spd, skh)
+            eng.update_begin(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed, offset=offset, noise=noise)
+            xw = self._exchange_records(eng)
+            yield
+            xw.wait()
+            mask = draws.get("balance_mask")
+            eng.update_finish(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed, offset=offset, noise=noise,
+                              balance_mask=mask)
+            if mask is not None:      # balancing a row-split tensor needs max |q| over ALL its rows (psgd.py:266-275)
+                eng.balance_shards([k for k in shard_k if mask[k]], self._reduce_max)
+
         if eng is not None:
-            own_p, back = _packed([self._data_of(plist[i]) for i in b.owned])      # (shadows only for strided parameters)
-            grads = [self._grad_of(plist[i]) for i in b.owned]
-            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
             coupled = wd if (wd > 0.0 and not decoupled) else 0.0
+            # the parameters themselves are needed here only for coupled weight decay and for the non-sharded update (the sharded path
+            # updates ALL parameters from the gathered buffer in _bucket_finish): no packed shadows of strided parameters otherwise
+            own_p, back = _packed([mine(i, self._data_of(plist[i])) for i in b.owned]) if (coupled or not self.shard_state) else (None, [])
+            grads = [mine(i, self._grad_of(plist[i])) for i in b.owned]
+            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
             damp = None
             if (updateP_first or updateP_last) and self._replay is None:
                 # the update that follows in this step reads G + (damping + eps|G|) * noise: let the momentum pass write it
@@ -437,9 +544,11 @@ class KWNS4(torch.optim.Optimizer):
             eng.accumulate(grads, params=own_p if coupled else None, coupled_wd=coupled, beta=beta,
                            keep_grad=bool(group["whiten_grad"]) or momentum == 0.0, damp=damp)
             if updateP_first:
-                eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
-                                   offset=2 * t, **self._update_draws(b, plist))
+                yield from update(2 * t)
             eng.precond_grad(src_p)
+            if shard_k:
+                # the RMS clip of a row-split tensor averages over ALL its rows (..._ddp.py:153-155): the blocks' sums of h^2 are summed
+                self._reduce_sum(eng.hsumsq, shard_k)
             if not self.shard_state:
                 eng.apply_update(own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
                 _unpack(back)
@@ -457,9 +566,24 @@ class KWNS4(torch.optim.Optimizer):
                 # hold CUs while it starts could run it into its spin limit (one skipped update + a permanent fall-back to the
                 # multi-launch route): let the exchange land first.  The multi-launch route overlaps freely.
                 work.wait()
-            eng.update_precond(src_w, group["lr_preconditioner"], group["betaL"], group["damping"], seed=self._seed,
-                               offset=2 * t + 1, **self._update_draws(b, plist))
+            yield from update(2 * t + 1)
         return work
+
+    def _exchange_records(self, eng):
+        """All-gather (in place; gloo: through a clone of this rank's record) of the row blocks' exchange records: the partial mode Grams
+        and diagonal maxima of include/psgdk.h "row shards".  Asynchronous."""
+        x, n = eng.xchg, eng.xchg_record_bytes
+        mine = x[self.rank * n:(self.rank + 1) * n]
+        in_place = torch.distributed.get_backend() == "nccl"
+        return torch.distributed.all_gather_into_tensor(x, mine if in_place else mine.clone(), async_op=True)
+
+    def _reduce_max(self, t):
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+
+    def _reduce_sum(self, hsumsq, ks):
+        """Sum over the ranks of the entries `ks` of the engine's per-tensor sums of h^2 (one float each; contiguous runs in one call)."""
+        for k in ks:
+            torch.distributed.all_reduce(hsumsq[k:k + 1], op=torch.distributed.ReduceOp.SUM)
 
     def _exchange(self, b):
         """ONE exchange step of a sharded bucket: all-gather of the clipped preconditioned gradients (bf16 when the preconditioner
@@ -519,7 +643,9 @@ class KWNS4(torch.optim.Optimizer):
         if self.shard_state:
             work.wait()
             present = {id(p) for p in plist}
-            lps, back = _packed([self._data_of(p) if id(p) in present else None for p in b.params])
+            whole, back = _packed([self._data_of(p) if id(p) in present else None for p in b.params])
+            # one entry per piece of the exchange: the tensor, or its row block (contiguous rows of the packed tensor)
+            lps = [None if whole[i] is None else (whole[i] if r0 is None else whole[i][r0:r1]) for i, r0, r1, _ in b.pieces]
             b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
             _unpack(back)
         b.step += 1
@@ -590,6 +716,7 @@ class KWNS4(torch.optim.Optimizer):
                 "param_groups": groups, "split": split, "split_owner": split_owner, "shard_chunks": self._shard_chunks,
                 "chunks": [{"parts": parts(k), "of": dict(v)} for k, v in self._chunks.items()],
                 "owners": None if self._legacy_owners else [{"parts": parts(k), "of": dict(v)} for k, v in self._owners.items()],
+                "rowsplit": [{"parts": parts(k), "of": {int(q): [list(x) for x in bl] for q, bl in v.items()}} for k, v in self._rowsplit.items()],
                 "dQ": self.dQ, "global_step": self._global_step, "gate_rng": self._gate_gen.get_state(), "seed": self._seed, "buckets": buckets}
 
     def load_state_dict(self, sd):
@@ -605,6 +732,19 @@ class KWNS4(torch.optim.Optimizer):
         assert len(sd["param_groups"]) == len(self.param_groups), "checkpoint does not match this optimizer"
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             assert len(saved["params"]) == len(g["params"]), "checkpoint does not match this optimizer"
+        # buckets that exist already must fit what the checkpoint holds for them (with shard_state=True the arenas and the lists of owned
+        # tensors are those of ONE rank: a checkpoint is restored by the rank that wrote it)
+        def _norm0(ks):
+            f = ks.split("|")
+            f[3] = self._dev_str(self._dev_from_str(f[3]))
+            return "|".join(f)
+        saved_b = {_norm0(k): v for k, v in sd["buckets"].items()}
+        for key, b in self._buckets.items():
+            sv = saved_b.get(self._key_str(key))
+            if sv is not None and (sv["n_params"] != len(b.params) or sv["owned"] != list(b.owned)):
+                raise ValueError(f"checkpoint bucket {self._key_str(key)} holds {sv['n_params']} parameters, owned {sv['owned']}; this optimizer's "
+                                 f"bucket has {len(b.params)}, owned {list(b.owned)} -- a sharded checkpoint belongs to the rank that wrote it "
+                                 "(same world size, same shard_chunks / shard_split_rows)")
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})
         self._global_step = sd["global_step"]
@@ -619,6 +759,7 @@ class KWNS4(torch.optim.Optimizer):
             return (int(gi), _dt(pdt), _dt(gdt), self._dev_from_str(dev)) + tuple(parts[4:])
         for e in sd.get("split_owner", []):
             self._split_owner[_key(e["parts"])] = list(e["owner"])
+        self._chunks = {}
         for e in sd.get("chunks", []):
             self._chunks[_key(e["parts"])] = {int(k): int(v) for k, v in e["of"].items()}
         # owners of chunked buckets: as saved; a checkpoint that has none (rounds 1-3) chose them chunk by chunk -- keep doing so, the
@@ -627,6 +768,9 @@ class KWNS4(torch.optim.Optimizer):
         self._legacy_owners = sd.get("owners") is None
         for e in (sd.get("owners") or []):
             self._owners[_key(e["parts"])] = {int(k): int(v) for k, v in e["of"].items()}
+        # row-split tensors: as saved (a checkpoint without the entry was taken before round 4: nothing is split, and stays so)
+        self._rowsplit = {_key(e["parts"]): {int(q): [tuple(x) for x in bl] for q, bl in e["of"].items()} for e in (sd.get("rowsplit") or [])}
+        self._rowsplit_frozen = True
         for e in sd.get("split", []):
             key = _key(e["parts"])
             if key not in self._split:

@@ -54,6 +54,37 @@ def _plan(lib, shapes, max_size=float("inf"), max_skew=1.0, dtype=0, mom=1):
     return rc, plan
 
 
+def test_row_shard_declaration_is_validated(lib):
+    from psgd_torch_amd import _lib
+    """psgdk_plan_set_row_shard (host-only part of the row-shard ABI): a row block must be a matrix with a diagonal dim-0 factor and a
+    dense dim-1 factor -- for the block's own shape AND for the whole matrix --, inside the whole matrix, declared once, with one
+    (member, members) per plan, in the default geometry; the exchange record holds the fp32 partial Gram + a scalar slot per shard."""
+    shapes = [(128, 32), (32, 32), (64,), (256, 32)]
+    rc, plan = _plan(lib, shapes)
+    assert rc == 0
+    rb = C.c_size_t(123)
+    assert lib.psgdk_plan_exchange_bytes(plan, C.byref(rb)) == 0 and rb.value == 0
+    E = _lib.PSGDK_ERR_INVALID
+    assert lib.psgdk_plan_set_row_shard(plan, 1, 512, 0, 0, 4) == E          # (32, 32): both factors dense
+    assert lib.psgdk_plan_set_row_shard(plan, 2, 512, 0, 0, 4) == E          # a vector
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 448, 0, 4) == E        # rows 448 .. 576 of 512
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 0, 4, 4) == E          # member out of range
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 0, 0, 1) == E          # one member is not a split
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 16, 0, 0, 2) == E           # whole matrix (16, 32): dim 0 would be dense
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 128, 1, 4) == 0
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 128, 1, 4) == E        # declared twice
+    assert lib.psgdk_plan_set_row_shard(plan, 3, 1024, 256, 2, 4) == E       # another member index in the same plan
+    assert lib.psgdk_plan_set_row_shard(plan, 3, 1024, 256, 1, 4) == 0
+    assert lib.psgdk_plan_exchange_bytes(plan, C.byref(rb)) == 0
+    assert rb.value == 2 * ((64 * 64 * 4 + 256 + 255) // 256 * 256)          # dp = 64 for the 32-wide factor
+    assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_EQ) == _lib.PSGDK_ERR_UNSUPPORTED
+    lib.psgdk_plan_destroy(plan)
+    rc, plan = _plan(lib, shapes)
+    assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_QEQ) == 0
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 128, 1, 4) == _lib.PSGDK_ERR_UNSUPPORTED
+    lib.psgdk_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("max_size,max_skew", [(float("inf"), 1.0), (float("inf"), float("inf")), (30, float("inf")),
                                                (float("inf"), 0.0), (float("inf"), 2.0), (100, 0.5)])
 def test_plan_factor_kinds_match_init_kron_rule(lib, max_size, max_skew):
@@ -239,33 +270,50 @@ def test_sharded_chunks_are_balanced_and_ordered():
         assert chunk[0] == 3, "wte (the first tensor) sits in the last chunk"
 
 
-def test_owners_balance_the_total_over_the_chunks():
-    """Owners of a chunked bucket come from ONE greedy over all its tensors (sharding.assign_owners): a rank's total over the chunks bounds
-    the arithmetic (the exchanges are asynchronous).  GPT-2-small at world 8: the wte owner carries wte and nothing else (1.78 x the mean,
-    its floor under whole-tensor ownership); the chunk-by-chunk greedy of rounds 1-3 put three more matrices on it (2.5 x).  World 4 and
-    GPT-2-medium are level."""
-    from psgd_torch_amd.sharding import assign_owners, chunk_partition, kron_step_cost, lpt_partition
-    import bench
+def _exchange_layout(shapes, world, n_chunks=4, split=True):
+    """Owners, per-rank loads and per-(chunk, rank) exchange segments (elements) as KWNS4 lays a sharded bucket out (kwns4.py:
+    _buckets_for / _bucket_for), from the sharding functions alone."""
+    import math
+    from psgd_torch_amd.sharding import assign_owners, chunk_partition, kron_step_cost, row_split_candidates
+    costs = [kron_step_cost(s) for s in shapes]
+    sp = row_split_candidates(shapes, costs, world) if split else {}
+    unit = [c if i not in sp else max(kron_step_cost((b[1] - b[0], shapes[i][1])) for b in sp[i]) for i, c in enumerate(costs)]
+    chunk = chunk_partition(unit, n_chunks, world)
+    owner = assign_owners(unit, chunk, n_chunks, world, split=list(sp))
+    assert owner == assign_owners(unit, chunk, n_chunks, world, split=list(sp))          # deterministic
+    loads = [sum(c for c, o in zip(unit, owner) if o in (r, -1)) for r in range(world)]
+    seg = [[0] * world for _ in range(n_chunks)]
+    for i, s in enumerate(shapes):
+        if i in sp:
+            for r, (a, b) in enumerate(sp[i]):
+                seg[chunk[i]][r] += ((b - a) * s[1] + 7) // 8 * 8
+        else:
+            seg[chunk[i]][owner[i]] += ((math.prod(s) if s else 1) + 7) // 8 * 8
+    return sp, owner, loads, seg
 
-    def max_load(costs, owner, world):
-        loads = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
-        return max(loads) / (sum(loads) / world)
-    for shapes, world, bound in ((bench.gpt2_shapes(), 8, 1.80), (bench.gpt2_shapes(), 4, 1.02), (bench.gpt2_shapes(), 2, 1.02),
-                                 (bench.gpt2_shapes(n_layer=24, n_embd=1024), 8, 1.05)):
-        costs = [kron_step_cost(s) for s in shapes]
-        chunk = chunk_partition(costs, 4, world)
-        owner = assign_owners(costs, chunk, 4, world)
-        assert owner == assign_owners(costs, chunk, 4, world) and set(owner) == set(range(world))
-        assert max_load(costs, owner, world) <= bound, (world, max_load(costs, owner, world))
-        old = [0] * len(costs)
-        for j in range(4):
-            idx = [k for k in range(len(costs)) if chunk[k] == j]
-            for k, r in zip(idx, lpt_partition([costs[k] for k in idx], world)):
-                old[k] = r
-        assert max_load(costs, owner, world) <= max_load(costs, old, world) + 1e-12
-    costs = [kron_step_cost(s) for s in bench.gpt2_shapes()]
-    owner = assign_owners(costs, chunk_partition(costs, 4, 8), 4, 8)
-    assert [o for o in owner].count(owner[0]) == 1, "the wte owner owns nothing else at world 8"
+
+def test_owner_map_levels_totals_and_chunk_segments():
+    """The owner map of a sharded bucket (sharding.assign_owners + row_split_candidates) on the real parameter lists.  GPT-2-small at 8
+    ranks: the tied embedding (1.78 x a rank's fair share as a whole tensor) is split by rows over all ranks, the largest rank carries
+    <= 1.05 x the mean load, and no rank contributes more than 15 MB (bf16) to any chunk's exchange -- round 3: one 77 MB source.
+    Where the embedding stays whole (2 ranks; GPT-2-medium up to 4 ranks) the totals are level to 2 % as well."""
+    import bench
+    small, medium = bench.gpt2_shapes(), bench.gpt2_shapes(n_layer=24, n_embd=1024)
+    for shapes, world, split_expected, max_load, max_seg_mb in ((small, 8, True, 1.05, 15.0), (small, 4, True, 1.02, 30.0), (small, 2, False, 1.03, 80.0),
+                                                              (medium, 8, True, 1.03, 35.0), (medium, 4, False, 1.03, 105.0)):
+        sp, owner, loads, seg = _exchange_layout(shapes, world)
+        assert (0 in sp) == split_expected and set(sp) <= {0}, (world, sp.keys())
+        if split_expected:
+            blocks = sp[0]
+            assert len(blocks) == world and blocks[0][0] == 0 and blocks[-1][1] == shapes[0][0]
+            assert all(b[0] % 64 == 0 and b[1] > b[0] for b in blocks) and all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+            assert owner[0] == -1
+        assert {o for o in owner if o >= 0} == set(range(world))
+        assert max(loads) / (sum(loads) / world) <= max_load, (world, max(loads) / (sum(loads) / world))
+        assert max(max(c) for c in seg) * 2 / 1e6 <= max_seg_mb, (world, [max(c) * 2 / 1e6 for c in seg])
+    # without the row split the embedding's owner carries it alone and nothing else (its floor: 1.78 x)
+    sp, owner, loads, seg = _exchange_layout(small, 8, split=False)
+    assert not sp and owner.count(owner[0]) == 1 and 1.7 < max(loads) / (sum(loads) / 8) < 1.8
 
 
 def test_flop_model_matches_survey():

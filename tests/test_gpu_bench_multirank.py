@@ -34,6 +34,10 @@ def test_bench_two_ranks_one_device(mode):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert out["config"]["state_finite_after_timed_region"] is True
+    # the ranks' parameters were compared bit for bit after the timed region (a checksum, all-reduced min / max): finite is not enough
+    # (replicas agree to rounding only: their fp32 atomics are unordered -- the reference resyncs them every resync_every steps)
+    if "sharding" in out["config"]["parallelism"]:
+        assert out["config"]["ranks_agree_bitwise"] is True
     if mode == "auto":       # the warm-up probe timed all three modes and the line says which one ran
         assert sorted(out["config"]["parallelism_probe_ms"]) == ["replicated", "sharded", "sharded, one exchange", "sharded, p2p"], out["config"]
         assert all(v > 0 for v in out["config"]["parallelism_probe_ms"].values())

@@ -32,7 +32,11 @@ def per_kernel(path, counter):
 def main():
     f = per_kernel(sys.argv[1], "FETCH_SIZE")
     w = per_kernel(sys.argv[2], "WRITE_SIZE")
-    res = {"note": "rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 3 --warmup 1`. "
+    import hashlib, os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psgd_torch_amd", "libpsgdk.so")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
+    res = {"library_sha256": sha,      # (bench.py compares it with the library it runs: roofline.traffic_stale)
+           "note": "rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 3 --warmup 1`. "
                    "read bytes = 2 x FETCH_SIZE x 1024 (gfx950: 64 B counted per 128-B request), write bytes = WRITE_SIZE x 1024.",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):
