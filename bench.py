@@ -166,12 +166,15 @@ def bench_lra(args):
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     N, r = 86543080, args.lra_rank
+    dt_ = torch.bfloat16 if args.bf16 else torch.float32
+    esz = 2 if args.bf16 else 4
     gen = torch.Generator(device=dev).manual_seed(0)
     U = torch.randn(N, r, device=dev, generator=gen); U *= 0.1 ** 0.5 / torch.linalg.vector_norm(U)
     V = torch.randn(N, r, device=dev, generator=gen); V *= 0.1 ** 0.5 / torch.linalg.vector_norm(V)
-    UVd = [U, V, torch.ones(N, 1, device=dev)]
+    UVd = [U.to(dt_), V.to(dt_), torch.ones(N, 1, device=dev, dtype=dt_)]
+    del U, V
     Luvd = [torch.zeros([], device=dev) for _ in range(3)]
-    g = 0.01 * torch.randn(N, 1, device=dev, generator=gen)
+    g = (0.01 * torch.randn(N, 1, device=dev, generator=gen)).to(dt_)
 
     def one_step():
         lra.update_precond_lra_whiten(UVd, Luvd, g, lr=0.1, betaL=0.9, damping=1e-9)
@@ -184,8 +187,8 @@ def bench_lra(args):
         one_step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
-    bytes_alg = (12 + 3) * N * r * 4 + (18 + 3) * N * 4        # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
-    bytes_moved = (12 + 3) * N * r * 4 + 24 * N * 4             # what the kernels move since round 3 (24 vector passes)
+    bytes_alg = (12 + 3) * N * r * esz + (18 + 3) * N * esz    # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
+    bytes_moved = (12 + 3) * N * r * esz + 24 * N * esz         # what the kernels move since round 3 (24 vector passes)
     peaks = None
     if not args.no_peaks:
         import ctypes as C
@@ -199,7 +202,7 @@ def bench_lra(args):
                  "what": "streaming 16-byte copy (read + write) / read of 1 GiB, best of 3, measured in this process after the timed region"}
     traffic = None          # HBM bytes per update + apply from the separate rocprofv3 --pmc passes (profiles/), all LRA launches summed
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_vit-b-lra_latest.json")
-    if os.path.exists(tpath) and r == 10:
+    if os.path.exists(tpath) and r == 10 and not args.bf16:
         try:
             tj = json.load(open(tpath))["kernels"]
             per_step = {}
@@ -212,8 +215,8 @@ def bench_lra(args):
             traffic = None
     out = {"metric": "psgd_lra_update_apply_throughput", "value": N / dt / 1e9, "unit": "Gparam/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "fp32", "data": "synthetic",
-           "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, fp32: update_precond_lra_whiten + precond_grad_lra",
+           "dtype": "bf16" if args.bf16 else "fp32", "data": "synthetic",
+           "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, {'bf16' if args.bf16 else 'fp32'}: update_precond_lra_whiten + precond_grad_lra",
                       "rank": r},
            "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": traffic,
@@ -306,6 +309,7 @@ def main():
                                                                   "under which the preconditioner actually moves while timed")
     ap.add_argument("--no-peaks", action="store_true", help="skip the in-process ceiling measurement (roofline.peak_measured)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
+    ap.add_argument("--bf16", action="store_true", help="vit-b-lra only: bf16 factors and vectors instead of fp32 (SURVEY 8d quotes both)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
                     help="BASELINE.json configs; the default (gpt2-small) is the headline metric's configuration")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to smoke-test "

@@ -37,7 +37,7 @@ extern "C" {
 enum {
     PSGDK_OK = 0,
     PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
-    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built yet (LRA rank > 64) */
+    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built (LRA rank > 1024; row shards outside the default geometry) */
     PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
     PSGDK_ERR_STATE = 4,       /* call order violated (e.g. arenas not bound) */
     PSGDK_ERR_NLB_TIMEOUT = 5  /* returned ONCE by the first psgdk_update_precond_* call after a cooperative norm-bound launch of an
@@ -230,7 +230,8 @@ int psgdk_fill_normal(void* out, int dtype, int64_t n, uint64_t seed, uint64_t o
 /* ===================================================================================================================
  * LRA preconditioner Q = (I + U V^T) diag(d) on the concatenated parameter vector (psgd.py:987-1072).
  * U, V: N x r row-major, d: N, element type = dtype (PSGDK_BF16 | PSGDK_F32), all caller-owned device memory;
- * Luvd: 3 fp32 device scalars (Lu, Lv, Ld; psgd.py:1123).  r <= 64 (three rank classes: 1, 2, 4 threads per row for r <= 16, 32, 64).
+ * Luvd: 3 fp32 device scalars (Lu, Lv, Ld; psgd.py:1123).  r <= 64: three tuned rank classes (1, 2, 4 threads per row for r <= 16, 32, 64); 64 < r <= 1024: a general path
+ * (one wavefront per row, r x r matrices in global memory) -- the same stages and rounding points, written for generality.
  * =================================================================================================================== */
 typedef struct psgdk_lra psgdk_lra;
 int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype);

@@ -8,6 +8,7 @@
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
 #include "kernels_lra.hiph"
+#include "kernels_lra_gen.hiph"
 #include "kernels_gen.hiph"
 #include "kernels_eq.hiph"
 #include "kernels_probe.hiph"
@@ -28,8 +29,6 @@ struct Stage {                       // one grouped GEMM launch
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
-    bool mid = false;                // 256 x 128 / 8-wave persistent tiling (gemm_nt_mid_kernel)
-    bool late_f2 = false;            // experiment: its LATE_F2 instantiation
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -146,8 +145,8 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
-    tb.bm = s.big ? GEMM_BIG_BM : (s.mid ? GEMM_MID_BM : (s.ksplit ? 64 : GEMM_BM));
-    tb.bn = s.big ? GEMM_BIG_BN : (s.mid ? GEMM_MID_BN : (s.ksplit ? 64 : GEMM_BN));
+    tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
+    tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
@@ -159,14 +158,6 @@ int finish_stage(Stage& s) {
 // A stage whose problems make at most this many tiles of 128 x 128 runs on 64 x 64 tiles with the K loop split over the workgroup's waves
 // (gemm_nt_ks_kernel; round 4, measured: LeNet5's step 0.234 -> 0.195 ms, profiles/r04_a_ksplit.md)
 static constexpr int64_t kKsplitMaxTiles = 64;
-// PSGDK_GEMM_MID (experiment while it is being measured; read at every bind): "1" = stages of at least 512 tiles of 256 x 128 that do not
-// take the 256 x 256 tiling run on gemm_nt_mid_kernel; a number = that threshold
-static int64_t mid_min_tiles() {
-    const char* e = getenv("PSGDK_GEMM_MID");
-    if (!e || !e[0] || e[0] == '0') return -1;
-    const int64_t v = atoll(e);
-    return v <= 1 ? 512 : v;
-}
 static int64_t big_min_tiles() {      // (read at every bind: the tests force the big tiling onto small plans with it)
     const char* e = getenv("PSGDK_BIG_MIN_TILES");
     return e ? (int64_t)atoll(e) : (int64_t)768;
@@ -189,10 +180,6 @@ void launch_stage_t(const Stage& s, hipStream_t st) {
     if (s.big && s.lock) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
     else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
                                        s.d_probs, s.d_tiles, (int)s.n_tiles);
-    else if (s.mid && s.late_f2) hipLaunchKernelGGL((gemm_nt_mid_kernel<T, true>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
-                                                    s.d_probs, s.d_tiles, (int)s.n_tiles);
-    else if (s.mid) hipLaunchKernelGGL((gemm_nt_mid_kernel<T, false>), dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st, s.d_probs,
-                                       s.d_tiles, (int)s.n_tiles);
     else if (s.ksplit) hipLaunchKernelGGL(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else if (s.ext) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
@@ -906,20 +893,9 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
         // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
-        // the middle tiling for what stays off the 256 x 256 one: many problems of moderate size (the 62 x 768^3 stages of GPT-2-small)
-        s->mid = false;
-        if (const int64_t mmin = mid_min_tiles(); mmin > 0 && !s->big && !s->ext && !s->probs.empty()) {
-            int64_t nm = 0;
-            for (const GemmProblem& g : s->probs) {
-                const int64_t tm = (g.M + GEMM_MID_BM - 1) / GEMM_MID_BM, tn = (g.N + GEMM_MID_BN - 1) / GEMM_MID_BN;
-                const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
-                nm += ((g.flags & GF_SYM) ? (tm * tn + tm) / 2 : tm * tn) * nks;       // (symmetric: roughly the upper half)
-            }
-            s->mid = nm >= mmin;
-        }
         // small launches: few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
         s->ksplit = false;
-        if (!s->big && !s->mid && !s->ext && !s->probs.empty()) {
+        if (!s->big && !s->ext && !s->probs.empty()) {
             const int bk = P->dtype == PSGDK_BF16 ? 64 : 32;
             int64_t n128 = 0;
             bool ok = true;
@@ -1954,10 +1930,8 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
     s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop,
-    s.lock = (symmetric & 2048) != 0;         // bit 24 the 256 x 128 tiling, bit 25 the 64 x 64 K-split one
-    s.mid = (symmetric & (1 << 24)) != 0;
+    s.lock = (symmetric & 2048) != 0;         // bit 25 the 64 x 64 K-split one
     s.ksplit = (symmetric & (1 << 25)) != 0;
-    s.late_f2 = (symmetric & (1 << 26)) != 0;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -1984,13 +1958,7 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 2) s.one_per_tile = true;
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
-    if (variant == 13 || variant == 17) { alt.probs = s.probs; alt.mid = true; alt.late_f2 = variant == 17; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 14) { alt.probs = s.probs; int rc = finish_stage(alt); if (rc) return rc; s = alt; }     // the 128 x 128 tiling, whatever was bound
-    if (variant == 15 || variant == 16) {     // the middle tiling without its epilogue / without its stores
-        alt.probs = s.probs; alt.mid = true;
-        for (auto& q : alt.probs) q.flags |= (variant == 15 ? GF_DBG_NOEPI : GF_DBG_NOSTORE);
-        int rc = finish_stage(alt); if (rc) return rc; s = alt;
-    }
     if (variant >= 5 && variant <= 12) {      // same tiling, parts of the epilogue's work stripped / the output discarded
         alt.probs = s.probs; alt.big = s.big;
         for (auto& q : alt.probs) {
@@ -2039,7 +2007,7 @@ int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int 
         if (!C && Ct) P.flags |= GF_TMAJOR;
         s->probs.push_back(P);
         s->big = (flags & 1024) != 0; s->lock = (flags & 2048) != 0; s->one_per_tile = (flags & 16384) != 0;
-        s->mid = (flags & (1 << 24)) != 0; s->ksplit = (flags & (1 << 25)) != 0;
+        s->ksplit = (flags & (1 << 25)) != 0;
         int rc = finish_stage(*s);
         if (rc) return rc;
         cache.push_back({Key{A, B, C, Ct, dtype, M, N, K, flags}, s});
@@ -2070,9 +2038,7 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.big = (symmetric & 1024) != 0;
     s.lock = (symmetric & 2048) != 0;
     s.one_per_tile = (symmetric & 16384) != 0;
-    s.mid = (symmetric & (1 << 24)) != 0;
     s.ksplit = (symmetric & (1 << 25)) != 0;
-    s.late_f2 = (symmetric & (1 << 26)) != 0;
     for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (7 << 24));
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -2206,11 +2172,12 @@ static int lra_sm_total(int tpr) { return tpr == 1 ? LraCfg<1>::TOTAL : (tpr == 
 
 int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype) {
     if (!out || N <= 0 || r < 0 || (r > 0 && r >= N) || (dtype != PSGDK_BF16 && dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
-    if (r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;        // valid upstream (any rank); the kernels hold r <= 64
+    // r <= 64: the three tuned rank classes; above: the general path (kernels_lra_gen.hiph), whose lanes keep 16 columns each
+    if (r > LRAG_RMAX) return PSGDK_ERR_UNSUPPORTED;       // (valid upstream -- any rank -- but an N x 1024 factor pair is 8 KB per element)
     psgdk_lra* L = new psgdk_lra();
     L->N = N; L->r = r; L->dtype = dtype; L->esz = dtype == PSGDK_BF16 ? 2 : 4;
     size_t wo = 0;
-    L->sm_off = wo; wo += align256((size_t)lra_sm_total(lra_tpr_of_rank(r)) * 4);
+    L->sm_off = wo; wo += align256((size_t)(r > LRA_RMAX ? lrag_layout(r).TOTAL : lra_sm_total(lra_tpr_of_rank(r))) * 4);
     const size_t nb = align256((size_t)N * L->esz);
     L->v_off = L->h_off = 0;      // (v and h are no longer materialised: LraVH)
     L->qh_off = wo; wo += nb; L->iq_off = wo; wo += nb;
@@ -2252,6 +2219,60 @@ static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* g
     *shm = bytes;
 }
 
+// ranks above 64: the general path (kernels_lra_gen.hiph), stage for stage the tuned one
+static int lra_update_general(psgdk_lra* L, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u, float lr,
+                              float betaL, float damping, hipStream_t st) {
+    const int64_t N = L->N; const int r = L->r;
+    const LragLayout Y = lrag_layout(r);
+    float* sm = (float*)(L->work + L->sm_off);
+    HIPCHK(hipMemsetAsync(sm, 0, (size_t)(Y.SC + 7) * 4, st));       // everything but the sum of h^2 of the last apply
+    const unsigned tiles = (unsigned)((r + 15) / 16);
+    const unsigned slices = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4096 / ((int64_t)tiles * tiles) + 1, 1024), (N + 255) / 256));
+    const unsigned gw = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + 3) / 4, 2048));
+    const unsigned shm_rot = (unsigned)(4 * 2 * r * sizeof(float));
+#define LRAG_T(...) do { if (L->dtype == PSGDK_BF16) { typedef bf16_t T; __VA_ARGS__; } else { typedef float T; __VA_ARGS__; } } while (0)
+    LRAG_T({
+        T* Qh = (T*)(L->work + L->qh_off); T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
+        T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
+        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset};
+        hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU, sm + Y.VTV,
+                           (float*)nullptr, 3);
+        hipLaunchKernelGGL(lrag_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
+        if (shm_rot > 64u * 1024u)
+            HIPCHK(hipFuncSetAttribute((const void*)lrag_rotate_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rot));
+        hipLaunchKernelGGL(lrag_rotate_kernel<T>, dim3(gw), dim3(256), shm_rot, st, U, V, (const T*)d, vh, N, sm, Y);
+        hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU2, sm + Y.VTV2,
+                           sm + Y.VTU, 7);
+        hipLaunchKernelGGL(lrag_small2_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
+        hipLaunchKernelGGL(lrag_pass3_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, Qh, iq, N, sm, Y);
+        hipLaunchKernelGGL(lrag_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, Y);
+        hipLaunchKernelGGL(lrag_pass4_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, (const T*)Qh, (const T*)iq,
+                           diff, N, sm, Y);
+        hipLaunchKernelGGL(lrag_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, Y, update_u ? 1 : 0, lr, betaL);
+        hipLaunchKernelGGL(lrag_pass5_kernel<T>, dim3(gw), dim3(256), 0, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff, N,
+                           update_u ? 1 : 0, (const float*)sm, Y);
+    });
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+static int lra_apply_general(psgdk_lra* L, const void* g, void* out, hipStream_t st) {
+    const int64_t N = L->N; const int r = L->r;
+    const LragLayout Y = lrag_layout(r);
+    float* sm = (float*)(L->work + L->sm_off);
+    HIPCHK(hipMemsetAsync(sm + Y.VTX2, 0, (size_t)(2 * r) * 4, st));
+    HIPCHK(hipMemsetAsync(sm + Y.SC + 7, 0, 4, st));
+    const unsigned gw = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + 3) / 4, 2048));
+    LRAG_T({
+        T* y = (T*)(L->work + L->y_off);
+        for (int stage = 0; stage < 3; ++stage)
+            hipLaunchKernelGGL(lrag_apply_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)L->U, (const T*)L->V, (const T*)L->d, (const T*)g, y,
+                               (T*)out, N, stage, sm, Y);
+    });
+#undef LRAG_T
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
 int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
                             float lr, float betaL, float damping, void* stream) {
     if (!lra || !g) return PSGDK_ERR_INVALID;
@@ -2261,6 +2282,7 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
     hipStream_t st = (hipStream_t)stream;
     float* sm = (float*)(L->work + L->sm_off);
     const int64_t N = L->N; const int r = L->r;
+    if (r > LRA_RMAX) return lra_update_general(L, g, v_noise, seed, offset, update_u, lr, betaL, damping, st);
     const int tpr = lra_tpr_of_rank(r), rm = 16 * tpr;
     const unsigned gb = (unsigned)std::min<int64_t>((N + 255) / 256, 2048);
     unsigned gb1, gb2, gbr, shm1, shm2, shmr;
@@ -2311,6 +2333,7 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
     psgdk_lra* L = lra;
     hipStream_t st = (hipStream_t)stream;
     float* sm = (float*)(L->work + L->sm_off);
+    if (L->r > LRA_RMAX) return lra_apply_general(L, g, out, st);
     unsigned gb1, shm1;
     lra_geometry(L->N, L->r, 1, 0, &gb1, &shm1);
     LRA_T(L, {
@@ -2328,6 +2351,7 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
 int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr) {
     if (!lra || !dev_ptr) return PSGDK_ERR_INVALID;
     if (!lra->work) return PSGDK_ERR_STATE;
+    if (lra->r > LRA_RMAX) { *dev_ptr = (const float*)(lra->work + lra->sm_off) + lrag_layout(lra->r).SC + 7; return PSGDK_OK; }
     const int tpr = lra_tpr_of_rank(lra->r);
     *dev_ptr = (const float*)(lra->work + lra->sm_off) + (tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ));
     return PSGDK_OK;

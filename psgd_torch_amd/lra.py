@@ -203,8 +203,9 @@ class LRAWhiten:
         self._vec = _FlatVectors(self._params_with_grad, p0.dtype, p0.device)
         N, r = self._vec.N, int(rank_of_approximation)
         assert 0 <= r < N, "Rank r should be in range [0, number of total parameters)"
-        if r > 64:
-            raise NotImplementedError("the HIP LRA kernels hold rank <= 64 (psgdk_lra_create: PSGDK_ERR_UNSUPPORTED)")
+        if r > 1024:
+            raise NotImplementedError("the HIP LRA kernels hold rank <= 1024 (psgdk_lra_create: PSGDK_ERR_UNSUPPORTED); ranks above 64 take "
+                                      "the general path")
         dev, dt = self._vec.device, p0.dtype
 
         def unit_scaled():                                                   # psgd.py:1115-1118

@@ -679,6 +679,9 @@ def gen_lra():
     # the wider rank classes of the HIP kernels (two / four threads per row: r <= 32 / <= 64)
     gen_lra_case("n600_r32", 600, 32, ("fp64", "fp32"), T=3, seed=6, prefix="lrabig_")
     gen_lra_case("n1100_r48", 1100, 48, ("fp32", "bf16"), T=2, seed=7, prefix="lrabig_")
+    # above the three rank classes: the general path of the HIP kernels (64 < r <= 1024; the reference takes any rank, psgd.py:1113)
+    gen_lra_case("n400_r96", 400, 96, ("fp32", "bf16"), T=2, seed=8, prefix="lrabig_")
+    gen_lra_case("n300_r130", 300, 130, ("fp64", "fp32"), T=2, seed=9, prefix="lrabig_")
     gen_lrawhiten_case("grad_r5", seed=1, rank_of_approximation=5, preconditioner_init_scale=1.0)
     gen_lrawhiten_case("momentum_r3_last", seed=2, rank_of_approximation=3, preconditioner_init_scale=None,
                        momentum=0.9, whiten_grad=False, update_preconditioner_first=False, lr_params=0.01)

@@ -127,13 +127,13 @@ def test_plan_argument_errors(lib):
     assert rc == _lib.PSGDK_ERR_INVALID
     rc, plan = _plan(lib, [(4, 4)])
     assert rc == 0
-    # LRA: any rank is valid upstream; the kernels hold r <= 64 and say so (not "invalid")
+    # LRA: any rank is valid upstream; the kernels hold r <= 1024 (r <= 64 tuned, above: the general path) and say so (not "invalid")
     h = C.c_void_p()
-    assert lib.psgdk_lra_create(C.byref(h), 1000, 65, 0) == _lib.PSGDK_ERR_UNSUPPORTED
+    assert lib.psgdk_lra_create(C.byref(h), 4000, 1025, 0) == _lib.PSGDK_ERR_UNSUPPORTED
     assert lib.psgdk_lra_create(C.byref(h), 1000, -1, 0) == _lib.PSGDK_ERR_INVALID
     assert lib.psgdk_lra_create(C.byref(h), 8, 8, 0) == _lib.PSGDK_ERR_INVALID        # rank must stay below N
-    for rank in (16, 17, 32, 64):
-        assert lib.psgdk_lra_create(C.byref(h), 1000, rank, 0) == 0
+    for rank in (16, 17, 32, 64, 65, 200, 1024):
+        assert lib.psgdk_lra_create(C.byref(h), 4000, rank, 0) == 0
         lib.psgdk_lra_destroy(h)
     # compute entry points refuse to run before arenas are bound
     assert lib.psgdk_precond_grad(plan, 0, None) == _lib.PSGDK_ERR_STATE

@@ -60,21 +60,22 @@ def test_tensors_with_9_to_16_dims(shape, geom, max_skew):
 def test_tensors_with_20_and_26_dims(ndim, geom, steps):
     """The reference's limit itself: 26 dims (one einsum letter each, psgd.py:197-198) of extent 2 = 2^26 elements with 26 dense 2 x 2
     factors (4 <= numel: all dense at max_skew = 1), and 20 dims; PSGDK_MAX_DIMS noise slots per tensor are all in use.  The
-    26-dim case moves 67 M elements through 26 mode products and 26 mode Grams on both sides (the CPU oracle alone needs ~ 1 min):
-    it runs when PSGDK_SLOW_TESTS=1."""
-    if ndim == 26 and os.environ.get("PSGDK_SLOW_TESTS", "0") != "1":
-        pytest.skip("2^26-element 26-dim tensor: set PSGDK_SLOW_TESTS=1")
+    26-dim case moves 67 M elements through 26 mode products and 26 mode Grams on both sides: there every mode Gram is a sum of 2^25
+    products, where an fp32 reference carries its own rounding -- so that case is judged against the fp64 oracle on the same draws, by the
+    criterion of the bf16 tests (error vs fp64 <= 1.5 x the fp32 oracle's own + the usual bound).  PSGDK_SKIP_26DIM=1 leaves it out."""
+    if ndim == 26 and os.environ.get("PSGDK_SKIP_26DIM", "0") == "1":
+        pytest.skip("2^26-element 26-dim tensor: PSGDK_SKIP_26DIM=1")
     # the CPU oracle's strided 26-dim copies thrash when torch spreads them over every core of a 128-core host (minutes instead of
     # the ~20 s they take on 8 threads); the GPU side of this case takes 0.1 s (tools/diag_26dim.py)
     n = torch.get_num_threads()
-    torch.set_num_threads(min(n, 8))
+    torch.set_num_threads(min(n, 16))
     try:
-        _run_case(7100 + ndim, (2,) * ndim, 1.0, float("inf"), geom, steps=steps)
+        _run_case(7100 + ndim, (2,) * ndim, 1.0, float("inf"), geom, steps=steps, truth64=(ndim == 26))
     finally:
         torch.set_num_threads(n)
 
 
-def _run_case(seed, shape, max_skew, max_size, geom, steps=3):
+def _run_case(seed, shape, max_skew, max_size, geom, steps=3, truth64=False):
     import psgd_torch_amd as amd
     sq = tuple(s for s in shape if s != 1)                     # the wrappers squeeze first (..._ddp.py:124)
     upd_amd = {"Q0.5EQ1.5": amd.update_precond_kron_whiten_q0p5eq1p5, "EQ": amd.update_precond_kron_whiten_eq,
@@ -91,6 +92,7 @@ def _run_case(seed, shape, max_skew, max_size, geom, steps=3):
     kw = dict(Scale=0.7, max_size=max_size, max_skew=max_skew)
     QL, exprs = amd.init_kron(torch.zeros(sq, device=DEV), dQ=geom, **kw)
     QLo, kinds = orc.init_kron(torch.zeros(sq), **(dict(kw, Scale=0.7 ** 2) if p4 else kw))   # psgd.py:186-187
+    QL64 = orc.init_kron(torch.zeros(sq, dtype=torch.float64), **(dict(kw, Scale=0.7 ** 2) if p4 else kw))[0] if truth64 else None
     assert [q.dim() == 2 for q in QL[0]] == [k == "dense" for k in kinds], (shape, kinds)
     for t in range(steps):
         G = 0.5 * torch.randn(sq, generator=gen)
@@ -113,13 +115,34 @@ def _run_case(seed, shape, max_skew, max_size, geom, steps=3):
         h = amd.precond_grad_kron(QL, exprs, G.to(DEV))
         ho = orc.precond_grad_kron_4p(QLo[0], G) if p4 else orc.precond_grad_kron(QLo[0], G)
         tag = (seed, shape, max_skew, max_size, geom, t)
-        assert relerr(h, ho) <= tol, tag + ("h", relerr(h, ho))
+        if truth64:
+            # the same draws through the fp64 oracle = truth; the engine may be as far from it as 1.5 x the fp32 oracle is (+ the bound)
+            assert geom == "Q0.5EQ1.5"
+            nz64 = orc.KronNoise(nz.g_noise.double(), [None if x is None else x.double() for x in nz.spd],
+                                 [None if x is None else x.double() for x in nz.skh], nz.balance_u)
+            upd_orc(QL64, G.double(), nz64, lr=0.2, betaL=0.9, damping=1e-6)
+            h64 = orc.precond_grad_kron(QL64[0], G.double())
+            e_hip, e_ref = relerr(h, h64), relerr(ho, h64)
+            assert e_hip <= 1.5 * e_ref + tol, tag + ("h vs fp64", e_hip, e_ref)
+            for i in range(len(QL[0])):
+                e_hip, e_ref = relerr(P_of([QL[0][i]])[0], P_of([QL64[0][i]])[0]), relerr(P_of([QLo[0][i]])[0], P_of([QL64[0][i]])[0])
+                assert e_hip <= 1.5 * e_ref + tol, tag + (i, "P vs fp64", e_hip, e_ref)
+                e_hip, e_ref = relerr(QL[1][i], QL64[1][i]), relerr(QLo[1][i], QL64[1][i])
+                assert e_hip <= 1.5 * e_ref + tol, tag + (i, "L vs fp64", e_hip, e_ref)
+            continue
+        # (errors into plain floats BEFORE the assert: on a failure pytest's rewritten assert prints the repr of every operand, and the
+        #  repr of a 26-dim tensor walks 2^26 Python frames -- the "hang" of the 26-dim case in round 3 was a failing assert being printed)
+        e_h = relerr(h, ho)
+        assert e_h <= tol, tag + ("h", e_h)
         for i in range(len(QL[0])):
             if geom == "Q0.5EQ1.5":                            # Q is gauge dependent there (Procrustes on rounding noise)
-                assert relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0]) <= tol, tag + (i, "P")
+                e_q = relerr(P_of([QL[0][i]])[0], P_of([QLo[0][i]])[0])
+                assert e_q <= tol, tag + (i, "P", e_q)
             else:
-                assert relerr(QL[0][i], QLo[0][i]) <= tol, tag + (i, "Q")
-            assert relerr(QL[1][i], QLo[1][i]) <= tol, tag + (i, "L")
+                e_q = relerr(QL[0][i], QLo[0][i])
+                assert e_q <= tol, tag + (i, "Q", e_q)
+            e_l = relerr(QL[1][i], QLo[1][i])
+            assert e_l <= tol, tag + (i, "L", e_l)
 
 
 M_CASES = int(os.environ.get("PSGDK_FUZZ_KWNS4", "12"))
@@ -180,12 +203,12 @@ L_CASES = int(os.environ.get("PSGDK_FUZZ_LRA", "24"))
 
 @pytest.mark.parametrize("seed", list(range(L_CASES)))
 def test_random_lra_case_matches_oracle(seed):
-    """LRA update + apply with random N (ragged against the 256- / 128- / 64-row blocks of the three rank classes), rank 0..64,
-    both update branches; fp32."""
+    """LRA update + apply with random N (ragged against the 256- / 128- / 64-row blocks of the three rank classes), rank 0..64 and,
+    through the general path, up to 200; both update branches; fp32."""
     from psgd_torch_amd import lra
     rnd = random.Random(9000 + seed)
     N = rnd.choice([1, 2, 17, 63, 65, 127, 129, 255, 256, 257, 511, 1000, 2049, 5000])
-    r = min(rnd.choice([0, 1, 2, 5, 10, 16, 17, 24, 32, 33, 47, 64]), max(N - 1, 0))
+    r = min(rnd.choice([0, 1, 2, 5, 10, 16, 17, 24, 32, 33, 47, 64, 65, 100, 129, 200]), max(N - 1, 0))
     gen = torch.Generator().manual_seed(9100 + seed)
     U = torch.randn(N, r, generator=gen); V = torch.randn(N, r, generator=gen)
     if r:
