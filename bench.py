@@ -251,7 +251,7 @@ def bench_eq(args):
         one_step(i)
     eng.profile_read(reset=True)
     eng.profile_enable(False)
-    sample = 4 if args.steps >= 8 else 1            # (event pairs around the GEMM launches on every 4th step only: see main())
+    sample = 10 if args.steps >= 20 else (4 if args.steps >= 8 else 1)            # (event pairs around the GEMM launches on every 4th step only: see main())
     prof_steps = 0
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -443,9 +443,10 @@ def main():
         e.profile_read(reset=True)
         e.profile_enable(False)
     # hipEvents around every grouped-GEMM launch (for the roofline object) cost ~4 us each: they fence the launch stream
-    # between kernels, 0.13 ms per GPT-2-small step.  So only every `sample`-th step of the timed region carries them; the
+    # between kernels, 0.13 ms per GPT-2-small step.  So only every `sample`-th step of the timed region carries them (every 10th of the
+    # default 30: three sampled steps, 27 launches); the
     # roofline's launch durations are those steps' launches, measured live on the launch stream inside the timed region.
-    sample = 4 if args.steps >= 8 else 1
+    sample = 10 if args.steps >= 20 else (4 if args.steps >= 8 else 1)
     prof_steps = 0
 
     # the collector's work inside the timed region is reported next to the host time (config.gc_in_timed_region): a full
