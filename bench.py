@@ -378,8 +378,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    MODES = {"sharded": dict(shard_state=True),                         # 4 chunks: each chunk's all-gather under the next one's arithmetic
+    MODES = {"sharded": dict(shard_state=True),                         # 2 chunks: the first chunk's all-gather under the second one's arithmetic
              "sharded, one exchange": dict(shard_state=True, shard_chunks=1),
+             "sharded, four chunks": dict(shard_state=True, shard_chunks=4),
              "sharded, p2p": dict(shard_state=True, shard_exchange="p2p"),       # every chunk as 2 (N - 1) direct sends / receives
 
              "replicated": dict(shard_state=False), "single": dict(shard_state=False)}
@@ -405,7 +406,7 @@ def main():
         mode = "replicated"
     if dist and args.parallelism == "auto":
         timing, failures = {}, []
-        for name in ("sharded", "sharded, one exchange", "sharded, p2p", "replicated"):
+        for name in ("sharded", "sharded, one exchange", "sharded, four chunks", "sharded, p2p", "replicated"):
             # (a mode that raises -- e.g. a collective the installed RCCL / torch refuses -- is dropped from the probe on every rank
             #  alike: argument errors are deterministic; the timed region then runs with what is left)
             try:
@@ -580,9 +581,10 @@ def main():
                                + ("; KWNS4 defaults (momentum 0.9, whiten momentum, update probability 1, max_skew 1)" if not args.whiten_grad
                                   else "; KWNS4 defaults except whiten_grad=True (momentum 0.9, update probability 1, max_skew 1)"),
                    "preconditioner_dtype": "fp32" if args.fp32 else "bf16", "param_dtype": "fp32",
-                   "parallelism": "single GPU" if world == 1 else ({"sharded": f"per-parameter state sharding x{world}, all-gathers of 4 chunks overlapped with the arithmetic",
+                   "parallelism": "single GPU" if world == 1 else ({"sharded": f"per-parameter state sharding x{world}, all-gathers of 2 chunks overlapped with the arithmetic",
                                                                     "sharded, one exchange": f"per-parameter state sharding x{world} + one all-gather per step",
-                                                                    "sharded, p2p": f"per-parameter state sharding x{world}, 4 chunks exchanged by direct point-to-point sends"}.get(
+                                                                    "sharded, four chunks": f"per-parameter state sharding x{world}, all-gathers of 4 chunks overlapped with the arithmetic",
+                                                                    "sharded, p2p": f"per-parameter state sharding x{world}, 2 chunks exchanged by direct point-to-point sends"}.get(
                                                                        mode, f"replicas x{world} (no exchange step)")),
                    "parallelism_probe_ms": ({k: (v * 1e3 if math.isfinite(v) else None) for k, v in timing.items()}
                                             if (dist and args.parallelism == "auto") else None),

@@ -11,7 +11,7 @@ What is different, on purpose:
   * `shard_state=True` (new; the reference only replicates): every rank owns a cost-balanced subset of
     the parameters, preconditions only those, and the clipped preconditioned gradients are exchanged by all-gather
     (RCCL over xGMI); every rank then applies the identical parameter update.  The tensors are worked off in
-    `shard_chunks` (default 4) cost-balanced chunks, each with its own exchange buffer: chunk c's asynchronous, in-place
+    `shard_chunks` (default 2) cost-balanced chunks, each with its own exchange buffer: chunk c's asynchronous, in-place
     all-gather travels while chunk c + 1 is preconditioned, and the parameter updates follow chunk by chunk as the
     gathers land -- on a step this short the fabric, not the arithmetic, is the critical path (DESIGN.md section 6);
   * (round 4) a DOMINANT matrix whose dim-0 factor is diagonal and whose dim-1 factor is dense (GPT-2's tied embedding) is SPLIT BY ROWS
@@ -70,6 +70,15 @@ class _Works:
         if self.after is not None:
             self.after()
             self.after = None
+
+
+# Chunks of the sharded step when the caller names none.  Every chunk is a plan of its own: ~20 dependent launches whose latency floor
+# (two cooperative norm bounds, stages of a handful of tiles) does not shrink with the chunk -- measured with tools/rank_arithmetic.py
+# (one rank's kernels of an 8-rank job, no wire; profiles/r04_g): GPT-2-small 0.81 / 1.12 / 1.60 ms per step at 1 / 2 / 4 chunks,
+# GPT-2-medium 1.91 / 2.18 / 2.94 -- about 0.3 ms per extra chunk, on the device, with the host only half as busy.  A chunk pays when the
+# exchange it hides takes longer than that: at 8 ranks a GPT-2-small step receives 218 MB (~0.7 ms at 300 GB/s), so two chunks hide what
+# one more plan costs, four never do (rounds 2-3 defaulted to 4 without this measurement).  bench.py's probe times 1, 2 and 4.
+DEFAULT_SHARD_CHUNKS = 2
 
 
 class _Bucket:
@@ -164,8 +173,8 @@ class KWNS4(torch.optim.Optimizer):
         self.rank = torch.distributed.get_rank() if self.is_distributed else 0
         self.shard_state = bool(shard_state) and self.world > 1
         # sharded mode: the tensors of a bucket are worked off in this many cost-balanced chunks, each with its own exchange
-        # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (default 4; 1 = one exchange)
-        self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else 4)) if self.shard_state else 1
+        # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (1 = one exchange)
+        self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else DEFAULT_SHARD_CHUNKS)) if self.shard_state else 1
         # how a chunk's clipped preconditioned gradients travel: "all_gather" (one collective; RCCL picks the algorithm) or "p2p"
         # (every rank sends its segment to each peer directly and receives theirs: 2 (N - 1) grouped point-to-point operations, all
         # seven xGMI links of a GPU busy at once -- a ring all-gather is bound by ONE link).  bench.py --parallelism auto times both.

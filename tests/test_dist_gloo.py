@@ -78,7 +78,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(whiten_grad=True, update_preconditioner_first=False, weight_decay=0.0),
+@pytest.mark.parametrize("kw", [dict(), dict(shard_chunks=4), dict(whiten_grad=True, update_preconditioner_first=False, weight_decay=0.0, shard_chunks=4),
                                 dict(preconditioner_update_probability=0.5, momentum=0.5),
                                 dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02),
                                 dict(shard_chunks=1), dict(shard_chunks=3, update_preconditioner_first=False),
@@ -100,13 +100,14 @@ def test_sharded_equals_replicated(kw):
         r1 = torch.load(os.path.join(d, "r1.pt"))
     if not kw.get("missing"):
         assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
-        # (default: 4 chunks per bucket, each with its own exchange; shard_chunks=1: one)
-        assert r0["n_buckets"] == min(kw.get("shard_chunks", 4), len(SHAPES)), r0["n_buckets"]
+        # (default: 2 chunks per bucket, each with its own exchange; shard_chunks=1: one)
+        from psgd_torch_amd.kwns4 import DEFAULT_SHARD_CHUNKS
+        assert r0["n_buckets"] == min(kw.get("shard_chunks", DEFAULT_SHARD_CHUNKS), len(SHAPES)), r0["n_buckets"]
         # both exchange forms are exercised: one chunk over two ranks is balanced (the collective over equal segments), the small
-        # chunks of the default setting are mostly padding (exact-size point-to-point exchange)
+        # chunks of a four-chunk setting are mostly padding (exact-size point-to-point exchange)
         if kw.get("shard_chunks") == 1 and kw.get("shard_exchange") != "p2p":
             assert not any(r0["uneven"]), r0["uneven"]
-        if "shard_chunks" not in kw:
+        if kw.get("shard_chunks") == 4:
             assert any(r0["uneven"]), r0["uneven"]
     for a, b, c in zip(r0["params"], r1["params"], ref_params):
         assert torch.equal(a, b), "ranks diverged"

@@ -39,7 +39,7 @@ def test_bench_two_ranks_one_device(mode):
     if "sharding" in out["config"]["parallelism"]:
         assert out["config"]["ranks_agree_bitwise"] is True
     if mode == "auto":       # the warm-up probe timed all three modes and the line says which one ran
-        assert sorted(out["config"]["parallelism_probe_ms"]) == ["replicated", "sharded", "sharded, one exchange", "sharded, p2p"], out["config"]
+        assert sorted(out["config"]["parallelism_probe_ms"]) == ["replicated", "sharded", "sharded, four chunks", "sharded, one exchange", "sharded, p2p"], out["config"]
         assert all(v > 0 for v in out["config"]["parallelism_probe_ms"].values())
     else:
         assert ("sharding" in out["config"]["parallelism"]) == (mode == "sharded")
@@ -71,4 +71,4 @@ def test_bench_two_ranks_over_rccl():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["state_finite_after_timed_region"] is True
     probe = out["config"]["parallelism_probe_ms"]
-    assert sorted(probe) == ["replicated", "sharded", "sharded, one exchange", "sharded, p2p"] and any(v for v in probe.values()), probe
+    assert sorted(probe) == ["replicated", "sharded", "sharded, four chunks", "sharded, one exchange", "sharded, p2p"] and any(v for v in probe.values()), probe

@@ -127,3 +127,50 @@ def test_cooperative_bound_timeout_is_reported_and_falls_back():
         eng.accumulate(grads, keep_grad=True)
         eng.update_precond(L.SRC_GRAD, 0.5, 0.9, 1e-9, seed=5, offset=0, balance_mask=[False] * 8)
     assert not w2
+
+
+@pytest.mark.parametrize("pd", [torch.float32, torch.bfloat16])
+def test_small_plans_are_bitwise_reproducible_and_plan_independent(pd):
+    """Replicas of a parameter (DTensor Replicate placements, DDP replicas) sit in engines of DIFFERENT composition on different ranks
+    and are resynced only now and then (..._dtensor.py:168-179): for factors that ONE 64 x 64 block covers every launch must be a pure
+    function of that tensor's own inputs -- no sum whose order depends on wave arrival, nothing that depends on what else is in the plan.
+    (Wider factors add three or more blocks' shares of a trace or a row sum with device atomics, like the reference's own kernels -- the reason
+    it resyncs at all, ..._ddp.py:163.)
+    (Round 4 found the narrow-factor instantiation of the cooperative bound adding four waves' row sums with LDS atomics: 1-ulp differences
+    of mu from run to run, visible in fp32 only.)  Three optimizers over clones of the same tensors: A, A again, and B whose second tensor
+    never has a gradient (one tensor fewer in its engine; same positions, hence the same Philox streams); 12 trials x 6 steps, all
+    states compared bit for bit.  First GPU run: A against A identical in all 3 x 12 trials after the fix; A against B differed where the
+    balancing gate had picked different tensors (the draws go one per tensor with a gradient) -- the gate is pinned here."""
+    import psgd_torch_amd
+    shapes = [(96, 64), (1, 80), (96,), (64, 64), (65, 40)]
+    bad = []
+    for trial in range(12):
+        g = torch.Generator().manual_seed(100 + trial)
+        init = [0.5 * torch.randn(s, generator=g) for s in shapes]
+        grads = [[0.3 * torch.randn(s, generator=g).to(DEV) for s in shapes] for _ in range(6)]
+        runs = []
+        for variant in ("A", "A", "B"):
+            ps = [torch.nn.Parameter(x.clone().to(DEV)) for x in init]
+            opt = psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, lr_params=1e-2, seed=trial)
+            # the host's gate draws (update: always at probability 1; balancing: 1 % per tensor) come one per tensor WITH a gradient, so the
+            # two compositions would balance different tensors on different steps -- host logic, not what is under test
+            opt._uniform = lambda: 0.5
+            for gs in grads:
+                for i, (p, gr) in enumerate(zip(ps, gs)):
+                    p.grad = None if (variant == "B" and i == 1) else gr
+                opt.step()
+            torch.cuda.synchronize()
+            st = {}
+            for i, p in enumerate(ps):
+                if variant == "B" and i == 1:
+                    continue
+                Q, Ls = opt.state[p]["QL"]
+                st[i] = [p.detach().clone()] + [q.clone() for q in Q] + [ell.clone() for ell in Ls] + [opt.state[p]["ema"].clone()]
+            runs.append(st)
+        for other, what in ((runs[1], "the same plan run twice"), (runs[2], "a plan with one tensor fewer")):
+            for i, ts in other.items():
+                for k, (a, b) in enumerate(zip(runs[0][i], ts)):
+                    if not torch.equal(a, b):
+                        bad.append(f"trial {trial}: tensor {i} {shapes[i]}, state item {k}: {what} differs by "
+                                   f"{float((a.float() - b.float()).abs().max()):.3e}")
+    assert not bad, "\n".join(bad[:40])
