@@ -175,6 +175,7 @@ class KWNS4(torch.optim.Optimizer):
         # sharded mode: the tensors of a bucket are worked off in this many cost-balanced chunks, each with its own exchange
         # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (1 = one exchange)
         self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else DEFAULT_SHARD_CHUNKS)) if self.shard_state else 1
+        self._shard_chunks_explicit = shard_chunks is not None      # (a checkpoint may bring its own count to an optimizer that named none)
         # how a chunk's clipped preconditioned gradients travel: "all_gather" (one collective; RCCL picks the algorithm) or "p2p"
         # (every rank sends its segment to each peer directly and receives theirs: 2 (N - 1) grouped point-to-point operations, all
         # seven xGMI links of a GPU busy at once -- a ring all-gather is bound by ONE link).  bench.py --parallelism auto times both.
@@ -737,7 +738,13 @@ class KWNS4(torch.optim.Optimizer):
         assert sd.get("psgdk_version") == 2, "not a psgd_torch_amd.KWNS4 state dict (version 2)"
         if sd.get("dQ", "Q0.5EQ1.5") != self.dQ:
             raise ValueError(f"checkpoint was taken with dQ={sd.get('dQ')!r}, this optimizer uses dQ={self.dQ!r}")
-        assert sd.get("shard_chunks", 1) == self._shard_chunks, "checkpoint was taken with another shard_chunks"
+        adopt_chunks = None
+        if sd.get("shard_chunks", 1) != self._shard_chunks:
+            # the chunk count decides which tensors share a plan: the arenas of a checkpoint fit only its own count.  An optimizer that was
+            # given none (the default changed from 4 to 2 in round 4) and has not built a bucket yet takes the checkpoint's
+            if not (self.shard_state and not self._shard_chunks_explicit and not self._buckets):
+                raise ValueError(f"checkpoint was taken with shard_chunks={sd.get('shard_chunks', 1)}, this optimizer uses {self._shard_chunks}")
+            adopt_chunks = int(sd["shard_chunks"])
         assert len(sd["param_groups"]) == len(self.param_groups), "checkpoint does not match this optimizer"
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             assert len(saved["params"]) == len(g["params"]), "checkpoint does not match this optimizer"
@@ -754,6 +761,8 @@ class KWNS4(torch.optim.Optimizer):
                 raise ValueError(f"checkpoint bucket {self._key_str(key)} holds {sv['n_params']} parameters, owned {sv['owned']}; this optimizer's "
                                  f"bucket has {len(b.params)}, owned {list(b.owned)} -- a sharded checkpoint belongs to the rank that wrote it "
                                  "(same world size, same shard_chunks / shard_split_rows)")
+        if adopt_chunks is not None:
+            self._shard_chunks = adopt_chunks
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})
         self._global_step = sd["global_step"]

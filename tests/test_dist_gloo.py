@@ -45,8 +45,16 @@ def _run(params, steps, shard, missing=False, resume=False, **kw):
     for t in range(steps):
         if resume and shard and t == 3:       # checkpoint / resume in the middle of the sharded run (after a bucket split, if any)
             sd = opt.state_dict()
+            if resume == "default_chunks":    # the resuming optimizer names no chunk count: it takes the checkpoint's
+                kw.pop("shard_chunks")
             opt = make()
             opt.load_state_dict(sd)
+            if resume == "default_chunks":
+                assert opt._shard_chunks == sd["shard_chunks"] == 4
+                import pytest
+                with pytest.raises(ValueError):       # ... one that names another count is refused
+                    psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=True,
+                                         shard_chunks=3).load_state_dict(sd)
         for i, p in enumerate(params):
             gr = 0.3 * torch.randn(p.shape, generator=g)
             p.grad = None if (missing and i in MISSING[t % len(MISSING)]) else gr
@@ -83,6 +91,7 @@ def _free_port():
                                 dict(missing=True), dict(missing=True, update_preconditioner_first=False, weight_decay=0.02),
                                 dict(shard_chunks=1), dict(shard_chunks=3, update_preconditioner_first=False),
                                 dict(missing=True, shard_chunks=2), dict(resume=True), dict(missing=True, resume=True),
+                                dict(resume="default_chunks", shard_chunks=4),
                                 dict(shard_exchange="p2p"), dict(shard_exchange="p2p", shard_chunks=1, update_preconditioner_first=False),
                                 dict(update_preconditioner_first=False, _coop=True), dict(update_preconditioner_first=False, _coop=True, shard_exchange="p2p")])
 def test_sharded_equals_replicated(kw):
