@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 4, call 13: non-temporal hints on the streaming passes (accumulate, emit), four libraries A/B/C/D/A on one box
+# round 4, calls 13 / 14 (HISTORICAL: the compile-time switch it used is gone, the winning mask is hard-coded in kernels_ew.hiph): non-temporal hints on the
+# streaming passes (accumulate, emit); the variants were built on the CPU box as psgd_torch_amd/libpsgdk_nt<mask>.so with -DPSGDK_EW_NT=<mask> and run
+# A/B/.../A on one box through tools/bench_with_lib.py.  Results: profiles/r04_i
 OUT=$(pwd)/gpurun_out/r04_nt2
 R=$(pwd)
 mkdir -p $OUT

@@ -15,7 +15,6 @@ are TIMES, the state is not a training state.  The exchanged bytes per step are 
 """
 import argparse
 import json
-import math
 import os
 import statistics
 import subprocess
