@@ -19,6 +19,12 @@ def run(M, N, K, batch, flags, label, iters=10):
     print(f"{os.path.basename(sys.argv[1]):20s} {label:30s} {M:6d} x {N:5d} x {K:5d}: {ms.value * 1e3:8.1f} us  {2.0 * M * N * K * batch / ms.value / 1e9:7.1f} TF/s", flush=True)
 
 
+which = sys.argv[2] if len(sys.argv) > 2 else "pipe"
+if which == "k128":
+    run(4096, 4096, 4096, 1, 256, "128x128 4096^3 no epilogue")
+    run(768, 768, 768, 62, 0, "128x128 62 x 768^3")
+    run(768, 768, 768, 62, 256, "128x128 62 x 768^3 no epilogue")
+    sys.exit(0)
 run(4096, 4096, 4096, 1, 1024, "4096^3")
 run(4096, 4096, 4096, 1, 1024 | 256, "4096^3 no epilogue")
 run(8192, 8192, 8192, 1, 1024 | 256, "8192^3 no epilogue")
