@@ -589,6 +589,7 @@ def main():
                    "parallelism_probe_ms": ({k: (v * 1e3 if math.isfinite(v) else None) for k, v in timing.items()}
                                             if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                   "step_device_ms": [round(x, 4) for x in per_step],      # every timed step, in order (event to event on the launch stream)
                    "gc_in_timed_region": gc_in_timed, "apply_only_ms_per_step": apply_only_ms,
                    "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products",
                    "norm_bound_timeouts": nlb_fallbacks, "state_finite_after_timed_region": True,

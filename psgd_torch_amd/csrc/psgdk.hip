@@ -4,6 +4,7 @@
 // and pre-builds, once, the grouped-GEMM problem/tile tables of every stage.  A step is then ~26 grouped launches
 // over ALL tensors (the reference issues ~100 ATen launches per tensor), with every scalar kept on the device.
 #include "host_util.hiph"
+#include "gemm_w4.hiph"
 #include "descs.hiph"
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
@@ -29,6 +30,8 @@ struct Stage {                       // one grouped GEMM launch
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
+    bool w4 = false;                 // (with big) the four-wave 256x256 kernel of gemm_w4.hiph: bf16 "fast" problems with K >= 128 only
+    int w4_var = 0;                  // experiments: its scheduling variant
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -177,7 +180,16 @@ static unsigned persistent_grid(unsigned n_tiles) {
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st) {
     if (!s.n_tiles) return;
-    if (s.big && s.lock) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
+    if (s.big && s.w4 && sizeof(T) == 2) {
+        const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
+        switch (s.w4_var) {
+            case 1: hipLaunchKernelGGL(gemm_nt_w4_kernel<8>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+            case 2: hipLaunchKernelGGL(gemm_nt_w4_kernel<2>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+            case 3: hipLaunchKernelGGL(gemm_nt_w4_kernel<3>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+            default: hipLaunchKernelGGL(gemm_nt_w4_kernel<4>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+        }
+    }
+    else if (s.big && s.lock) hipLaunchKernelGGL(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), 0, st, s.d_probs, s.d_tiles);
     else if (s.big) hipLaunchKernelGGL(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512), 0, st,
                                        s.d_probs, s.d_tiles, (int)s.n_tiles);
     else if (s.ksplit) hipLaunchKernelGGL(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), 0, st, s.d_probs, s.d_tiles);
@@ -1932,6 +1944,9 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop,
     s.lock = (symmetric & 2048) != 0;         // bit 25 the 64 x 64 K-split one
     s.ksplit = (symmetric & (1 << 25)) != 0;
+    s.w4 = (symmetric & (1 << 26)) != 0;      // bit 26 (with bit 10): the four-wave 256 x 256 kernel; bits 27-28 its scheduling variant
+    s.w4_var = (symmetric >> 27) & 3;
+    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128 || !gemm_is_fast_problem<bf16_t>(P))) return PSGDK_ERR_UNSUPPORTED;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -2039,7 +2054,11 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.lock = (symmetric & 2048) != 0;
     s.one_per_tile = (symmetric & 16384) != 0;
     s.ksplit = (symmetric & (1 << 25)) != 0;
-    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (7 << 24));
+    s.w4 = (symmetric & (1 << 26)) != 0;
+    s.w4_var = (symmetric >> 27) & 3;
+    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128)) return PSGDK_ERR_UNSUPPORTED;
+    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (31 << 24));
+    if (s.w4 && !gemm_is_fast_problem<bf16_t>(s.probs[0])) return PSGDK_ERR_UNSUPPORTED;
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
