@@ -186,6 +186,9 @@ void launch_stage_t(const Stage& s, hipStream_t st) {
             case 1: hipLaunchKernelGGL(gemm_nt_w4_kernel<8>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
             case 2: hipLaunchKernelGGL(gemm_nt_w4_kernel<2>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
             case 3: hipLaunchKernelGGL(gemm_nt_w4_kernel<3>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_w4_kernel<4, 1>), g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no DMA in the loop
+            case 5: hipLaunchKernelGGL((gemm_nt_w4_kernel<4, 2>), g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no barrier
+            case 6: hipLaunchKernelGGL((gemm_nt_w4_kernel<4, 3>), g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // neither
             default: hipLaunchKernelGGL(gemm_nt_w4_kernel<4>, g, dim3(256), 0, st, s.d_probs, s.d_tiles, (int)s.n_tiles); break;
         }
     }
@@ -905,6 +908,15 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
         // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
+        // the four-wave 256 x 256 kernel (gemm_w4.hiph, round 5) takes a big stage whose problems are all "fast" bf16 problems with at
+        // least two K steps: the two full-size products of a step (PSGDK_W4=0: the eight-wave kernel, for A/B runs)
+        s->w4 = false;
+        if (s->big && P->dtype == PSGDK_BF16) {
+            const char* e = getenv("PSGDK_W4");
+            bool ok = !(e && atoi(e) == 0);
+            for (const GemmProblem& g : s->probs) ok = ok && gemm_w4_takes(g);
+            s->w4 = ok;
+        }
         // small launches: few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
         s->ksplit = false;
         if (!s->big && !s->ext && !s->probs.empty()) {
@@ -1945,8 +1957,8 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     s.lock = (symmetric & 2048) != 0;         // bit 25 the 64 x 64 K-split one
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;      // bit 26 (with bit 10): the four-wave 256 x 256 kernel; bits 27-28 its scheduling variant
-    s.w4_var = (symmetric >> 27) & 3;
-    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128 || !gemm_is_fast_problem<bf16_t>(P))) return PSGDK_ERR_UNSUPPORTED;
+    s.w4_var = (symmetric >> 27) & 7;
+    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || !gemm_w4_takes(P))) return PSGDK_ERR_UNSUPPORTED;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -1974,8 +1986,19 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 14) { alt.probs = s.probs; int rc = finish_stage(alt); if (rc) return rc; s = alt; }     // the 128 x 128 tiling, whatever was bound
+    if (variant >= 20 && variant <= 27 && s.big) {      // the eight-wave (even) / four-wave (odd) 256 x 256 kernel: as is, no epilogue, no stores, register-direct stores
+        alt.probs = s.probs; alt.big = true; alt.w4 = (variant & 1) != 0;
+        for (auto& q : alt.probs) {
+            if ((variant >> 1) == 11) q.flags |= GF_DBG_NOEPI;
+            if ((variant >> 1) == 12) q.flags |= GF_DBG_NOSTORE;
+            if ((variant >> 1) == 13) q.flags |= GF_DBG_HALFLINES;
+            if (alt.w4 && !gemm_w4_takes(q)) return PSGDK_ERR_UNSUPPORTED;
+        }
+        if (alt.w4 && plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
     if (variant >= 5 && variant <= 12) {      // same tiling, parts of the epilogue's work stripped / the output discarded
-        alt.probs = s.probs; alt.big = s.big;
+        alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4;
         for (auto& q : alt.probs) {
             if (variant == 5 || variant == 6) { q.row_sumsq = nullptr; q.sumsq = nullptr; }
             if (variant == 6) { q.row_scale = nullptr; q.flags &= ~(GF_SQ_ROWSCALE | GF_RSQRT_ROWSCALE); }
@@ -2055,10 +2078,10 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.one_per_tile = (symmetric & 16384) != 0;
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;
-    s.w4_var = (symmetric >> 27) & 3;
+    s.w4_var = (symmetric >> 27) & 7;
     if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128)) return PSGDK_ERR_UNSUPPORTED;
-    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (31 << 24));
-    if (s.w4 && !gemm_is_fast_problem<bf16_t>(s.probs[0])) return PSGDK_ERR_UNSUPPORTED;
+    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (63 << 24));
+    if (s.w4 && !gemm_w4_takes(s.probs[0])) return PSGDK_ERR_UNSUPPORTED;
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
