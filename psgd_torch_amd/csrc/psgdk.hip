@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 #include "host_util.hiph"
 #include "gemm_w4.hiph"
+#include "gemm_w4p.hiph"
 #include "descs.hiph"
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
@@ -33,6 +34,7 @@ struct Stage {                       // one grouped GEMM launch
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
     bool w4 = false;                 // (with big) the four-wave 256x256 kernel of gemm_w4.hiph: bf16 "fast" problems with K >= 128 only
     int w4_var = 0;                  // experiments: its scheduling variant
+    bool w4p = false;                // (with big) the ping-pong four-wave kernel of gemm_w4p.hiph (256 x 128 tiles): gemm_w4p_takes() problems only
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -149,6 +151,7 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
+    tb.w4p = s.big && s.w4p;
     tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
     tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
@@ -188,7 +191,15 @@ static unsigned persistent_grid(unsigned n_tiles) {
 template <typename T>
 void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if (!s.n_tiles) return;
-    if (s.big && s.w4 && sizeof(T) == 2) {
+    if (s.big && s.w4p && sizeof(T) == 2) {
+        const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
+        switch (s.w4_var) {
+            case 4: PSGDK_LAUNCH(gemm_nt_w4p_kernel<5>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // timing: no epilogue, no DMA in the loop
+            case 7: PSGDK_LAUNCH(gemm_nt_w4p_kernel<4>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // timing: no epilogue
+            default: PSGDK_LAUNCH(gemm_nt_w4p_kernel<0>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
+        }
+    }
+    else if (s.big && s.w4 && sizeof(T) == 2) {
         const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
         switch (s.w4_var) {
             case 1: PSGDK_LAUNCH(gemm_nt_w4_kernel<8>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
@@ -918,10 +929,16 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
         // the four-wave 256 x 256 kernel (gemm_w4.hiph, round 5) takes a big stage whose problems are all "fast" bf16 problems with at
         // least two K steps: the two full-size products of a step (PSGDK_W4=0: the eight-wave kernel, for A/B runs)
-        s->w4 = false;
-        if (s->big && P->dtype == PSGDK_BF16) {
-            const char* e = getenv("PSGDK_W4");
+        s->w4 = false; s->w4p = false;
+        if (s->big && P->dtype == PSGDK_BF16) {      // the ping-pong kernel of gemm_w4p.hiph where it applies (PSGDK_W4P=0: not)
+            const char* e = getenv("PSGDK_W4P");
             bool ok = !(e && atoi(e) == 0);
+            for (const GemmProblem& g : s->probs) ok = ok && gemm_w4p_takes(g);
+            s->w4p = ok;
+        }
+        if (s->big && P->dtype == PSGDK_BF16 && !s->w4p) {
+            const char* e = getenv("PSGDK_W4");      // (round 5: measured equal to the eight-wave kernel inside the step; off unless asked for)
+            bool ok = e && atoi(e) != 0;
             for (const GemmProblem& g : s->probs) ok = ok && gemm_w4_takes(g);
             s->w4 = ok;
         }
@@ -1966,7 +1983,9 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;      // bit 26 (with bit 10): the four-wave 256 x 256 kernel; bits 27-28 its scheduling variant
     s.w4_var = (symmetric >> 27) & 7;
+    s.w4p = (symmetric & (1 << 23)) != 0;      // bit 23 (with bit 10): the ping-pong four-wave kernel
     if (s.w4 && (!s.big || dtype != PSGDK_BF16 || !gemm_w4_takes(P))) return PSGDK_ERR_UNSUPPORTED;
+    if (s.w4p && (!s.big || dtype != PSGDK_BF16 || !gemm_w4p_takes(P))) return PSGDK_ERR_UNSUPPORTED;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -2017,6 +2036,12 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
             if (variant == 11) q.flags |= GF_DBG_DESYNC;
             if (variant == 12) q.flags |= GF_DBG_DESYNC2;
         }
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
+    if (variant >= 30 && variant <= 32 && s.big) {      // the ping-pong four-wave kernel: as is, no epilogue, no epilogue and no DMA
+        alt.probs = s.probs; alt.big = true; alt.w4p = true; alt.w4_var = variant == 31 ? 7 : (variant == 32 ? 4 : 0);
+        if (plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
+        for (auto& q : alt.probs) if (!gemm_w4p_takes(q)) return PSGDK_ERR_UNSUPPORTED;
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -2087,9 +2112,11 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;
     s.w4_var = (symmetric >> 27) & 7;
+    s.w4p = (symmetric & (1 << 23)) != 0;
     if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128)) return PSGDK_ERR_UNSUPPORTED;
-    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (63 << 24));
+    for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (63 << 24) | (1 << 23));
     if (s.w4 && !gemm_w4_takes(s.probs[0])) return PSGDK_ERR_UNSUPPORTED;
+    if (s.w4p && (!s.big || dtype != PSGDK_BF16 || !gemm_w4p_takes(s.probs[0]))) return PSGDK_ERR_UNSUPPORTED;
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;

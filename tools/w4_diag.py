@@ -36,21 +36,16 @@ for rnd in range(int(os.environ.get('W4_DIAG_FIRST', '0'))):
         run(4096, 4096, 4096, 1, fl, f"w4 {nm}: 4096^3 no epilogue")
         run(8192, 8192, 8192, 1, fl, f"w4 {nm}: 8192^3 no epilogue", iters=4)
         run(131072, 768, 768, 1, fl, f"w4 {nm}: in-step X P no epilogue")
-DESYNC, DESYNC2 = 65536, 1 << 21
-HALF = 1 << 30
+W4P = 1 << 23
 for rnd in range(3):
-    for name, fl in (("w4", BIG | W4), ("pipe", BIG)):
+    for name, fl in (("ping-pong", BIG | W4P), ("w4", BIG | W4), ("pipe", BIG)):
         for tm in (False, True):
             t = " t-major" if tm else ""
             run(131072, 768, 768, 1, fl, f"{name}: in-step X P{t}", tmajor=tm)
-            if name == "w4":
-                run(131072, 768, 768, 1, fl | HALF, f"{name}: in-step X P{t} register-direct stores", tmajor=tm)
-                run(131072, 768, 768, 1, fl | DESYNC, f"{name}: in-step X P{t} desync 4", tmajor=tm)
-                run(131072, 768, 768, 1, fl | DESYNC2, f"{name}: in-step X P{t} desync 8", tmajor=tm)
-                run(131072, 768, 768, 1, fl | NOSTORE, f"{name}: in-step X P{t} no stores", tmajor=tm)
-            run(131072, 768, 768, 1, fl | NOEPI, f"{name}: in-step X P{t} no epilogue", tmajor=tm)
-    run(768, 768, 768, 62, 0, "128x128: 62 x 768^3")
-    run(768, 768, 768, 62, HALF, "128x128: 62 x 768^3 register-direct stores")
-    run(768, 768, 768, 62, BIG | W4, "w4: 62 x 768^3")
-    run(262144, 768, 768, 1, BIG | W4, "w4: 2x in-step X P")
-    run(262144, 768, 768, 1, BIG | W4 | DESYNC, "w4: 2x in-step X P desync 4")
+            run(131072, 768, 768, 1, fl | NOEPI if name != "ping-pong" else fl | (7 << 27), f"{name}: in-step X P{t} no epilogue", tmajor=tm)
+        if name == "ping-pong":
+            run(131072, 768, 768, 1, fl | (4 << 27), f"{name}: in-step X P no epilogue, no DMA")
+            run(131072, 768, 768, 1, fl | NOSTORE, f"{name}: in-step X P no stores")
+            run(4096, 4096, 4096, 1, fl | (7 << 27), f"{name}: 4096^3 no epilogue")
+            run(4096, 4096, 4096, 1, fl, f"{name}: 4096^3")
+            run(768, 768, 768, 62, fl, f"{name}: 62 x 768^3")
