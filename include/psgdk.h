@@ -289,12 +289,13 @@ int psgdk_update_precond_finish(psgdk_plan* plan, int source, float lr, float be
                                 uint64_t offset, const void* exchange, const uint8_t* balance_mask, void* stream);
 int psgdk_balance_phase(psgdk_plan* plan, const uint8_t* mask, int phase, void* stream);
 
-/* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): when enabled, every gemm_nt launch is
- * bracketed by hipEvents on the launch stream; psgdk_profile_read synchronises those events and returns the summed
- * launch time (ms) and the launch count since the last reset. */
+/* ---- live profiling of the grouped-GEMM launches (bench.py roofline line): with bit 0 of `enable` set, every grouped-GEMM launch
+ * carries a start / stop event pair on its own dispatch packet (hipExtLaunchKernelGGL: nothing extra on the stream);
+ * psgdk_profile_read synchronises those events and returns the summed launch time (ms) and the launch count since the last reset.
+ * Bit 1: the hot-path calls are bracketed too (below; recorded on the stream, ~4 us each). */
 int psgdk_profile_enable(psgdk_plan* plan, int enable);
 int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset);
-/* the same switch also brackets every hot-path CALL (accumulate, update, precond_grad, apply / export) by an event pair: the summed device
+/* bit 1 of the same switch brackets every hot-path CALL (accumulate, update, precond_grad, apply / export) by an event pair: the summed device
  * time between the first and the last kernel of each call, i.e. the engine's kernel time per step without the host in it. */
 int psgdk_profile_read_calls(psgdk_plan* plan, double* call_ms, int64_t* calls, int reset);
 

@@ -117,7 +117,8 @@ struct psgdk_plan {
     unsigned n_trsm_tiles[2] = {0, 0};
     UinvJob* d_uinv = nullptr; unsigned n_uinv = 0;
     // optional live profiling of the grouped-GEMM launches (bench.py roofline line)
-    bool prof = false;
+    bool prof = false;            // event pairs on the grouped-GEMM launches (ride on the dispatch packets: free)
+    bool prof_calls = false;      // event pairs around every hot-path call (hipEventRecord: they fence the stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev, prof_call_ev;
     size_t prof_used = 0, prof_call_used = 0;
 
@@ -240,7 +241,7 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
 // profiling (psgdk_profile_enable): an event pair around one hot-path call -- recorded on entry and when the call returns
 struct ProfCall {
     psgdk_plan* p; hipStream_t st; bool on;
-    ProfCall(psgdk_plan* plan, void* stream) : p(plan), st((hipStream_t)stream), on(plan && plan->prof && plan->state) {
+    ProfCall(psgdk_plan* plan, void* stream) : p(plan), st((hipStream_t)stream), on(plan && plan->prof_calls && plan->state) {
         if (!on) return;
         if (p->prof_call_used == p->prof_call_ev.size()) {
             hipEvent_t a, b;
@@ -1791,7 +1792,8 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
 
 int psgdk_profile_enable(psgdk_plan* plan, int enable) {
     if (!plan) return PSGDK_ERR_INVALID;
-    plan->prof = enable != 0;
+    plan->prof = (enable & 1) != 0;
+    plan->prof_calls = (enable & 2) != 0;      // (enable = 1: the launches only; 3: the calls too)
     return PSGDK_OK;
 }
 

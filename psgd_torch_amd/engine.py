@@ -446,8 +446,10 @@ class KronEngine:
         return out
 
     # live profiling of the grouped-GEMM launches (bench.py)
-    def profile_enable(self, on: bool = True):
-        L.check(self.lib.psgdk_profile_enable(self._plan, int(on)), "profile_enable")
+    def profile_enable(self, on: bool = True, calls: bool = False):
+        """on: an event pair on every grouped-GEMM launch (attached to the dispatch packet: no cost on the stream); calls: also an event
+        pair around every hot-path call (recorded on the stream: ~4 us each)."""
+        L.check(self.lib.psgdk_profile_enable(self._plan, (1 if on else 0) | (2 if (on and calls) else 0)), "profile_enable")
 
     @_on_device
     def profile_read(self, reset: bool = True):
