@@ -121,6 +121,7 @@ class KWNS4(torch.optim.Optimizer):
             shard_chunks: Optional[int] = None,
             shard_exchange: str = "all_gather",
             shard_split_rows=True,
+            shard_resync_every: int = 100,
             engine_factory=None,
     ):
         # the reference's argument checks, verbatim in meaning (..._ddp.py:45-62)
@@ -181,6 +182,8 @@ class KWNS4(torch.optim.Optimizer):
         # seven xGMI links of a GPU busy at once -- a ring all-gather is bound by ONE link).  bench.py --parallelism auto times both.
         assert shard_exchange in ("all_gather", "p2p")
         self._shard_exchange = shard_exchange
+        assert shard_resync_every > 0
+        self._shard_resync_every = int(shard_resync_every)      # period of the row-split tensors' replicated-factor resync (_bucket_finish)
         self._chunks = {}            # bucket key -> {position of the parameter in its group: chunk index}
         self._seed = int(seed)
         self._gate_gen = torch.Generator().manual_seed(self._seed)      # same stream on every rank
@@ -264,6 +267,10 @@ class KWNS4(torch.optim.Optimizer):
                 costs = [kron_step_cost(s, group["preconditioner_max_size"], group["preconditioner_max_skew"]) for s in shapes]
                 cand = row_split_candidates(shapes, costs, self.world, group["preconditioner_max_size"], group["preconditioner_max_skew"],
                                             threshold=self._split_rows_threshold)
+                # the blocks are cut as slices of dim 0 of the RAW gradient / parameter (x[r0:r1]): a tensor whose squeezed rows are not its
+                # raw dim 0 -- (1, N, M) squeezes to (N, M) -- would hand the engine the whole tensor or nothing.  Such tensors stay whole.
+                cand = {i: bl for i, bl in cand.items() if self._grad_of(plist[i]).dim() >= 1 and self._grad_of(plist[i]).shape[0] == shapes[i][0]
+                        and self._grad_of(plist[i]).numel() == shapes[i][0] * shapes[i][1]}
                 self._rowsplit[key] = {pos[id(plist[i])]: [tuple(b) for b in blocks] for i, blocks in cand.items()}
         if self._shard_chunks <= 1:
             return self._buckets_for_key(gi, group, plist, key)
@@ -491,7 +498,10 @@ class KWNS4(torch.optim.Optimizer):
             for it in paused:
                 while not run(it):
                     pass
-            for b, sub, _, work in items:
+            # finish in the order the exchanges were POSTED (row-split buckets post theirs last): waiting for the last-posted collective
+            # first would hold back the parameter updates of every chunk whose exchange landed long ago
+            done_first = [it for it in items if not any(it is q for q in paused)]
+            for b, sub, _, work in done_first + paused:
                 self._bucket_finish(b, group, sub, work)
         self._global_step += 1
         left = getattr(self, "_pending_restore", None)
@@ -584,8 +594,30 @@ class KWNS4(torch.optim.Optimizer):
         and diagonal maxima of include/psgdk.h "row shards".  Asynchronous."""
         x, n = eng.xchg, eng.xchg_record_bytes
         mine = x[self.rank * n:(self.rank + 1) * n]
-        in_place = torch.distributed.get_backend() == "nccl"
+        in_place = self._device_backend_is_rccl(x)
         return torch.distributed.all_gather_into_tensor(x, mine if in_place else mine.clone(), async_op=True)
+
+    @staticmethod
+    def _device_backend_is_rccl(t) -> bool:
+        """Is the transport that will carry device tensor `t` RCCL ("nccl")?  Asked of the default group's backend FOR THE TENSOR'S DEVICE:
+        init_process_group() without a backend, or with "cpu:gloo,cuda:nccl", reports a composite / undefined string through
+        get_backend(), and a string compare against "nccl" would then send a real RCCL job down the host-staged path (a .cpu() sync per
+        chunk) without a word."""
+        try:
+            pg = torch.distributed.group.WORLD
+            be = pg._get_backend(t.device) if hasattr(pg, "_get_backend") else None
+            name = be.name() if be is not None and hasattr(be, "name") else None
+            if name and name.lower() in ("nccl", "rccl"):
+                return True
+            if name and name.lower() in ("gloo", "mpi", "ucc"):
+                return False
+            # (anything else -- torch's fake group, a wrapper -- : the configured string decides)
+        except Exception:      # noqa: BLE001  (fake / wrapped groups: fall back to the configured string)
+            pass
+        cfg = str(torch.distributed.get_backend()).lower()
+        if t.is_cuda and "cuda:nccl" in cfg:
+            return True
+        return cfg == "nccl"
 
     def _reduce_max(self, t):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -612,7 +644,7 @@ class KWNS4(torch.optim.Optimizer):
             # are more than a quarter padding -- a collective over equal-size segments would move the padding too.
             used = b.used
             ops = []
-            if flat.is_cuda and torch.distributed.get_backend() != "nccl":
+            if flat.is_cuda and not self._device_backend_is_rccl(flat):
                 # Point-to-point operations are stream-ordered ONLY on RCCL (the collective stream waits for the current stream
                 # when the operation is posted, and work.wait() makes the current stream wait for it).  ProcessGroupGloo's
                 # send / recv take the RAW pointer: on device memory they read the segment through the BAR whenever the socket
@@ -644,7 +676,7 @@ class KWNS4(torch.optim.Optimizer):
                 if used[r] > 0:
                     ops.append(torch.distributed.P2POp(torch.distributed.irecv, flat[r * seg:r * seg + used[r]], r))
             return _Works(torch.distributed.batch_isend_irecv(ops) if ops else [])
-        in_place = torch.distributed.get_backend() == "nccl"
+        in_place = self._device_backend_is_rccl(flat)
         return torch.distributed.all_gather_into_tensor(flat, mine if in_place else mine.clone(), async_op=True)
 
     def _bucket_finish(self, b, group, plist, work):
@@ -664,6 +696,32 @@ class KWNS4(torch.optim.Optimizer):
         # ..._ddp.py:163-170: periodic resync of replicated state from rank 0 (drift from non-deterministic atomics)
         if self.is_distributed and not self.shard_state and (b.step % group["resync_every"] == 0):
             self._resync(b, plist)
+        # sharded mode: a row-split tensor's DENSE factor (and its L) is replicated on every member, and the members' copies drift like the
+        # reference's replicas do (norm-bound sums with unordered fp32 atomics for d > 512; a cooperative norm-bound time-out on ONE member
+        # makes that member skip an update its peers apply).  Same cure as ..._ddp.py:163-170, on a shorter period of its own: member 0's
+        # copy replaces the others'.
+        if self.shard_state and getattr(b, "blocks", None) and b.engine is not None and (b.step % self._shard_resync_every == 0):
+            self._resync_row_split(b)
+
+    def _resync_row_split(self, b):
+        """Broadcast of the replicated factors of this bucket's row-split tensors from member 0: every factor of a row block that is not the
+        row-sharded diagonal one (for the [diag, dense] structure row_split_candidates admits: the dense factor of dim 1) and its L."""
+        eng = b.engine
+        changed = False
+        for k, i in enumerate(b.owned):
+            if i not in b.rows:
+                continue
+            qs, ls = eng.QL(k)
+            for f in range(1, len(qs)):                 # factor 0 is the row-sharded one: each member owns its rows of it
+                q = qs[f]
+                t = q.contiguous()                      # (the dense factor is a strided view of the arena: row stride = padded d)
+                torch.distributed.broadcast(t, src=0)
+                if t.data_ptr() != q.data_ptr():
+                    q.copy_(t)
+                torch.distributed.broadcast(ls[f], src=0)
+                changed = True
+        if changed:
+            eng.state_changed()      # Q^T and the cached P = Q^T Q belong to the pre-resync factor
 
     def _resync(self, b, plist):
         # replicated mode: every rank holds the same bucket over the same tensors, so the whole state arena (Q, Q^T, diagonal

@@ -278,3 +278,55 @@ def test_row_split_world_of_eight_on_a_gpt2_shaped_list():
             #  ACROSS PROCESSES -- the BLAS picks its kernels by operand alignment -- so: one or two ulp)
             err = float((rs[0]["params"][k] - c.data).abs().max() / c.data.abs().max())
             assert err <= 3e-7 * steps, ("unsplit tensor differs from the single-process result", k, err)
+
+
+def _resync_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import psgd_torch_amd
+        from oracle_engine import OracleEngine
+        g = torch.Generator().manual_seed(7)
+        params = [torch.nn.Parameter(0.5 * torch.randn(s, generator=g)) for s in ROW_SHAPES]
+        opt = psgd_torch_amd.KWNS4(params, preconditioner_dtype=torch.float32, engine_factory=OracleEngine, shard_state=True, lr_params=1e-2,
+                                   shard_split_rows=0.0, shard_resync_every=3)
+        g = torch.Generator().manual_seed(99)
+        seen = []
+        for t in range(4):
+            for p in params:
+                p.grad = 0.3 * torch.randn(p.shape, generator=g)
+            opt.step()
+            if t == 0 and rank == 1:
+                # what a cooperative norm-bound time-out on ONE member leaves behind: that member's replicated dense factor (and its L)
+                # differs from its peers'
+                for b in opt._buckets.values():
+                    for k, i in enumerate(b.owned):
+                        if i in b.rows:
+                            b.engine.QL(k)[0][1].mul_(1.5)
+                            b.engine.QL(k)[1][1].add_(0.25)
+                            b.engine.state_changed()
+            facs = [(b.engine.QL(k)[0][1].clone(), b.engine.QL(k)[1][1].clone()) for b in opt._buckets.values() for k, i in enumerate(b.owned) if i in b.rows]
+            seen.append(facs)
+        torch.save(seen, os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_row_split_replicated_factors_are_resynced():
+    """The dense factor of a row-split tensor is replicated on every member; a member that falls out of step (a skipped update after a
+    norm-bound time-out, drift of unordered atomics) is brought back by the periodic broadcast from member 0 (shard_resync_every)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_resync_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
+    assert len(rs[0][0]) >= 1
+    for t in range(4):
+        same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(rs[0][t], rs[1][t]))
+        # steps 1 and 2 (t = 0, 1 after the perturbation): the members differ; the resync at the end of step 3 (b.step = 3) repairs it
+        assert same == (t >= 2), (t, same)
