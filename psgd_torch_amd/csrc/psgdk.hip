@@ -27,8 +27,7 @@ struct Stage {                       // one grouped GEMM launch
     GemmProblem* d_probs = nullptr;
     GemmTile* d_tiles = nullptr;
     unsigned n_tiles = 0;
-    bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_pipe_kernel; gemm_nt_big_kernel with `lock`)
-    bool lock = false;               // tests / experiments: the lock-step main loop of the 256x256 tiling
+    bool big = false;                // 256x256 / 8-wave tiling (gemm_nt_pipe_kernel)
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
@@ -216,7 +215,6 @@ void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hip
             default: PSGDK_LAUNCH(gemm_nt_w4_kernel<4>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
         }
     }
-    else if (s.big && s.lock) PSGDK_LAUNCH(gemm_nt_big_kernel<T>, dim3(s.n_tiles), dim3(512), s.d_probs, s.d_tiles);
     else if (s.big) PSGDK_LAUNCH(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512),
                                  s.d_probs, s.d_tiles, (int)s.n_tiles);
     else if (s.ksplit) PSGDK_LAUNCH(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles);
@@ -1991,8 +1989,7 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     P.alpha = 1.0f; P.flags = (symmetric & 1) ? GF_SYM : 0;
     if (symmetric & 1) { if (M != N || !C) return PSGDK_ERR_INVALID; P.Ct = C; P.ldct = ldc; }
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
-    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 11 its lock-step main loop,
-    s.lock = (symmetric & 2048) != 0;         // bit 25 the 64 x 64 K-split one
+    s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 25 the 64 x 64 K-split one
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;      // bit 26 (with bit 10): the four-wave 256 x 256 kernel; bits 27-28 its scheduling variant
     s.w4_var = (symmetric >> 27) & 7;
@@ -2021,7 +2018,7 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (which < 0 || which >= (int)(sizeof(list) / sizeof(list[0]))) return PSGDK_ERR_INVALID;
     Stage s = *list[which];              // shallow copy: shares the device tables unless the tiling changes
     Stage alt;
-    if (variant == 1) s.lock = true;
+    if (variant == 1) return PSGDK_ERR_UNSUPPORTED;      // (the lock-step 256x256 main loop: removed in round 5)
     if (variant == 2) s.one_per_tile = true;
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
@@ -2096,7 +2093,7 @@ int psgdk_test_gemm_launch(const void* A, const void* B, void* C, void* Ct, int 
         P.flags = flags & ~(1024 | 2048 | 16384 | (3 << 24));
         if (!C && Ct) P.flags |= GF_TMAJOR;
         s->probs.push_back(P);
-        s->big = (flags & 1024) != 0; s->lock = (flags & 2048) != 0; s->one_per_tile = (flags & 16384) != 0;
+        s->big = (flags & 1024) != 0; s->one_per_tile = (flags & 16384) != 0;
         s->ksplit = (flags & (1 << 25)) != 0;
         int rc = finish_stage(*s);
         if (rc) return rc;
@@ -2126,7 +2123,6 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
         s.probs.push_back(P);
     }
     s.big = (symmetric & 1024) != 0;
-    s.lock = (symmetric & 2048) != 0;
     s.one_per_tile = (symmetric & 16384) != 0;
     s.ksplit = (symmetric & (1 << 25)) != 0;
     s.w4 = (symmetric & (1 << 26)) != 0;
