@@ -935,8 +935,8 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // least two K steps: the two full-size products of a step (PSGDK_W4=0: the eight-wave kernel, for A/B runs)
         s->w4 = false; s->w4p = false;
         if (s->big && P->dtype == PSGDK_BF16) {      // the ping-pong kernel of gemm_w4p.hiph where it applies (PSGDK_W4P=0: not)
-            const char* e = getenv("PSGDK_W4P");
-            bool ok = !(e && atoi(e) == 0);
+            const char* e = getenv("PSGDK_W4P");      // (round 5: measured 8 - 10 % BEHIND the eight-wave kernel inside the step; only when asked for)
+            bool ok = e && atoi(e) != 0;
             for (const GemmProblem& g : s->probs) ok = ok && gemm_w4p_takes(g);
             s->w4p = ok;
         }
@@ -2027,6 +2027,11 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
         alt.probs = s.probs; alt.big = true; alt.w4 = true; alt.w4_var = 7;
         if (plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
         for (auto& q : alt.probs) { if (variant == 41) q.flags |= GF_DBG_NOEPI; if (!gemm_w4_takes(q)) return PSGDK_ERR_UNSUPPORTED; }
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
+    if (variant >= 50 && variant <= 53 && s.big) {      // the eight-wave kernel: register-direct (50, 51) / staged (52, 53) stores, in lock step (even) / start-staggered (odd)
+        alt.probs = s.probs; alt.big = true;
+        for (auto& q : alt.probs) { if (variant < 52) q.flags |= GF_DBG_HALFLINES; if (variant & 1) q.flags |= GF_DBG_DESYNC; }
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
     if (variant >= 20 && variant <= 27 && s.big) {      // the eight-wave (even) / four-wave (odd) 256 x 256 kernel: as is, no epilogue, no stores, register-direct stores
