@@ -2034,6 +2034,11 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
         for (auto& q : alt.probs) { if (variant < 52) q.flags |= GF_DBG_HALFLINES; if (variant & 1) q.flags |= GF_DBG_DESYNC; }
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
+    if (variant == 56) {      // as bound, output stores register-direct (16 rows x 64 B) instead of staged through the LDS
+        alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4; alt.w4p = s.w4p; alt.ksplit = s.ksplit; alt.ext = s.ext;
+        for (auto& q : alt.probs) q.flags |= GF_DBG_HALFLINES;
+        int rc = finish_stage(alt); if (rc) return rc; s = alt;
+    }
     if (variant >= 20 && variant <= 27 && s.big) {      // the eight-wave (even) / four-wave (odd) 256 x 256 kernel: as is, no epilogue, no stores, register-direct stores
         alt.probs = s.probs; alt.big = true; alt.w4 = (variant & 1) != 0;
         for (auto& q : alt.probs) {
