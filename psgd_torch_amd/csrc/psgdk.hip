@@ -32,8 +32,7 @@ struct Stage {                       // one grouped GEMM launch
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
     bool w4 = false;                 // (with big) the four-wave 256x256 kernel of gemm_w4.hiph: bf16 "fast" problems with K >= 128 only
-    int w4_var = 0;                  // experiments: its scheduling variant
-    bool rev = false;                // problems enter the tile table in reverse order: the launch starts with what its predecessor wrote LAST
+    int w4_var = 0;                  // timing experiments (test hooks): parts of its main loop / epilogue left out
     bool w4p = false;                // (with big) the ping-pong four-wave kernel of gemm_w4p.hiph (256 x 128 tiles): gemm_w4p_takes() problems only
 };
 
@@ -65,8 +64,6 @@ struct psgdk_plan {
     // device tables owned by the plan
     TensorDesc* d_td = nullptr; DiagDesc* d_dd = nullptr; DenseDesc* d_dn = nullptr;
     EwTile* d_tiles_all = nullptr; unsigned n_tiles_all = 0;
-    EwTile* d_tiles_rev = nullptr;                   // the same tiles, last tensor first
-    int rev_mask = 0;                                // PSGDK_REV (experiment): bit 0 upd_a, 1 gram, 2 app_a, 3 emit walk the tensors last-first
     std::vector<unsigned> tile_begin;                // per tensor range in d_tiles_all
     EwTile* d_tiles_diag = nullptr; unsigned n_tiles_diag = 0;
     PtrTableCache ptrs_a, ptrs_b;                           // device copies of the callers' pointer tables (gradients; parameters / outputs)
@@ -130,7 +127,7 @@ struct psgdk_plan {
 
     ~psgdk_plan() {
         auto fr = [](void* p) { if (p) (void)hipFree(p); };
-        fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_rev); fr(d_tiles_diag);
+        fr(d_td); fr(d_dd); fr(d_dn); fr(d_tiles_all); fr(d_tiles_diag);
         fr(d_noise_g); fr(d_noise_spd); fr(d_noise_skh); fr(d_scale_diag); fr(d_scale_dense); fr(d_balance); fr(d_gd);
         for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : prof_call_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -157,7 +154,7 @@ int finish_stage(Stage& s) {
     tb.w4p = s.big && s.w4p;
     tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
     tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
-    for (size_t k = 0; k < s.probs.size(); ++k) { const size_t i = s.rev ? s.probs.size() - 1 - k : k; tb.add_problem((int)i, s.probs[i]); }
+    for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
     std::vector<GemmTile> tiles = tb.finish();
     s.n_tiles = (unsigned)tiles.size();
     int rc = upload(&s.d_probs, s.probs);
@@ -205,13 +202,9 @@ void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hip
     else if (s.big && s.w4 && sizeof(T) == 2) {
         const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
         switch (s.w4_var) {
-            case 1: PSGDK_LAUNCH(gemm_nt_w4_kernel<8>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
-            case 2: PSGDK_LAUNCH(gemm_nt_w4_kernel<2>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
-            case 3: PSGDK_LAUNCH(gemm_nt_w4_kernel<3>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
             case 4: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 1>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no DMA in the loop
             case 5: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 2>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no barrier
             case 6: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 3>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // neither
-            case 7: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 8>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // with L2 touches three K steps ahead
             default: PSGDK_LAUNCH(gemm_nt_w4_kernel<4>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
         }
     }
@@ -637,7 +630,6 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     P->tile_begin[P->n_tensors] = (unsigned)all.size();
     P->n_tiles_all = (unsigned)all.size(); P->n_tiles_diag = (unsigned)diag.size();
     if ((rc = upload(&P->d_tiles_all, all))) return rc;
-    { std::vector<EwTile> r(all.rbegin(), all.rend()); if ((rc = upload(&P->d_tiles_rev, r))) return rc; }
     if ((rc = upload(&P->d_tiles_diag, diag))) return rc;
     auto alloc_ptrs = [&](void*** p, size_t n) -> int {
         if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -931,19 +923,20 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
         // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
         if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
-        // the four-wave 256 x 256 kernel (gemm_w4.hiph, round 5) takes a big stage whose problems are all "fast" bf16 problems with at
-        // least two K steps: the two full-size products of a step (PSGDK_W4=0: the eight-wave kernel, for A/B runs)
+        // The two four-wave 256 x 256 kernels of round 5 (accumulators in named AGPRs) can take a big stage whose problems are all "fast"
+        // bf16 problems -- the two full-size products of a step -- but only on request: inside the GPT-2-small step the plain one
+        // (gemm_w4.hiph, PSGDK_W4=1; main loop 13 % faster in isolation) measured EQUAL to the eight-wave kernel, the ping-pong one
+        // (gemm_w4p.hiph, PSGDK_W4P=1; epilogue of tile t - 1 interleaved with the main loop of tile t) 8 - 10 % BEHIND it.
         s->w4 = false; s->w4p = false;
-        if (s->big && P->dtype == PSGDK_BF16) {      // the ping-pong kernel of gemm_w4p.hiph where it applies (PSGDK_W4P=0: not)
-            const char* e = getenv("PSGDK_W4P");      // (round 5: measured 8 - 10 % BEHIND the eight-wave kernel inside the step; only when asked for)
+        if (s->big && P->dtype == PSGDK_BF16) {
+            const char* e = getenv("PSGDK_W4P");
             bool ok = e && atoi(e) != 0;
             for (const GemmProblem& g : s->probs) ok = ok && gemm_w4p_takes(g);
             s->w4p = ok;
         }
         if (s->big && P->dtype == PSGDK_BF16 && !s->w4p) {
-            const char* e = getenv("PSGDK_W4");      // (round 5: measured equal to the eight-wave kernel inside the step; off unless asked for)
+            const char* e = getenv("PSGDK_W4");
             bool ok = e && atoi(e) != 0;
-            s->w4_var = (e && atoi(e) == 2) ? 7 : 0;      // (2: with the L2 touches)
             for (const GemmProblem& g : s->probs) ok = ok && gemm_w4_takes(g);
             s->w4 = ok;
         }
@@ -963,10 +956,6 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             s->ksplit = ok && n128 <= kKsplitMaxTiles;
         }
     }
-    { const char* e = getenv("PSGDK_REV"); P->rev_mask = e ? atoi(e) : 0; }
-    P->g_upd_a.rev = (P->rev_mask & 1) != 0; P->g_upd_b.rev = P->g_upd_a.rev;
-    P->g_gram.rev = (P->rev_mask & 2) != 0;
-    P->g_app_a[0].rev = P->g_app_a[1].rev = P->g_app_b.rev = (P->rev_mask & 4) != 0;
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
     return PSGDK_OK;
@@ -1068,6 +1057,11 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
         }
         do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
     }
+    // PSGDK_EW_DBG (measurement switch, tools/ew_bench.py / ew_check.py): 1 = damped input without the noise (the pass's HBM floor; wrong
+    // results), 2 = the general path for every tile (same results as the compile-time-resolved path, bit for bit)
+    static const int ew_dbg = getenv("PSGDK_EW_DBG") ? atoi(getenv("PSGDK_EW_DBG")) : 0;
+    if (ew_dbg & 1) do_x |= do_x << 1;
+    if (ew_dbg & 2) do_x |= do_x << 2;
     DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
                                         plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,
                                         plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
@@ -1662,7 +1656,7 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
     void** d_params = nullptr;
     if ((rcp = plan->ptrs_b.get((const void* const*)params, plan->n_tensors, st, &d_params))) return rcp;
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
-                                        (plan->rev_mask & 8) ? plan->d_tiles_rev : plan->d_tiles_all,
+                                        plan->d_tiles_all,
                                         (void* const*)d_params, param_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp, (void*)nullptr));
     HIPCHK(hipGetLastError());
@@ -2023,17 +2017,6 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 3 && s.big) { alt.probs = s.probs; alt.big = false; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 14) { alt.probs = s.probs; int rc = finish_stage(alt); if (rc) return rc; s = alt; }     // the 128 x 128 tiling, whatever was bound
-    if (variant >= 40 && variant <= 41 && s.big) {      // the four-wave kernel with L2 touches: as is, no epilogue
-        alt.probs = s.probs; alt.big = true; alt.w4 = true; alt.w4_var = 7;
-        if (plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
-        for (auto& q : alt.probs) { if (variant == 41) q.flags |= GF_DBG_NOEPI; if (!gemm_w4_takes(q)) return PSGDK_ERR_UNSUPPORTED; }
-        int rc = finish_stage(alt); if (rc) return rc; s = alt;
-    }
-    if (variant >= 50 && variant <= 53 && s.big) {      // the eight-wave kernel: register-direct (50, 51) / staged (52, 53) stores, in lock step (even) / start-staggered (odd)
-        alt.probs = s.probs; alt.big = true;
-        for (auto& q : alt.probs) { if (variant < 52) q.flags |= GF_DBG_HALFLINES; if (variant & 1) q.flags |= GF_DBG_DESYNC; }
-        int rc = finish_stage(alt); if (rc) return rc; s = alt;
-    }
     if (variant == 56) {      // as bound, output stores register-direct (16 rows x 64 B) instead of staged through the LDS
         alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4; alt.w4p = s.w4p; alt.ksplit = s.ksplit; alt.ext = s.ext;
         for (auto& q : alt.probs) q.flags |= GF_DBG_HALFLINES;
@@ -2050,17 +2033,13 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
         if (alt.w4 && plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
-    if (variant >= 5 && variant <= 12) {      // same tiling, parts of the epilogue's work stripped / the output discarded
+    if (variant >= 5 && variant <= 8) {      // same tiling, parts of the epilogue's work stripped / the output discarded
         alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4;
         for (auto& q : alt.probs) {
             if (variant == 5 || variant == 6) { q.row_sumsq = nullptr; q.sumsq = nullptr; }
             if (variant == 6) { q.row_scale = nullptr; q.flags &= ~(GF_SQ_ROWSCALE | GF_RSQRT_ROWSCALE); }
             if (variant == 7) q.flags |= GF_DBG_NOSTORE;
             if (variant == 8) q.flags |= GF_DBG_NOEPI;
-            if (variant == 9) q.flags |= GF_DBG_TINYOUT;
-            if (variant == 10) q.flags |= GF_DBG_PLAINST;
-            if (variant == 11) q.flags |= GF_DBG_DESYNC;
-            if (variant == 12) q.flags |= GF_DBG_DESYNC2;
         }
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }

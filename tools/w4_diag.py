@@ -6,7 +6,7 @@ import torch
 from psgd_torch_amd import _lib
 lib = _lib.lib()
 dev = "cuda:0"
-BIG, W4, NOEPI, NOSTORE, TINYOUT, PLAINST = 1024, 1 << 26, 256, 4096, 131072, 32768
+BIG, W4, NOEPI, NOSTORE = 1024, 1 << 26, 256, 4096
 
 
 def run(M, N, K, batch, flags, label, iters=10, tmajor=False):
@@ -29,8 +29,6 @@ for rnd in range(int(os.environ.get('W4_DIAG_FIRST', '0'))):
             run(131072, 768, 768, 1, fl, f"{name}: in-step X P{t}", tmajor=tm)
             run(131072, 768, 768, 1, fl | NOEPI, f"{name}: in-step X P{t} no epilogue", tmajor=tm)
             run(131072, 768, 768, 1, fl | NOSTORE, f"{name}: in-step X P{t} no stores", tmajor=tm)
-            run(131072, 768, 768, 1, fl | TINYOUT, f"{name}: in-step X P{t} stores into 8 KiB", tmajor=tm)
-            run(131072, 768, 768, 1, fl | PLAINST, f"{name}: in-step X P{t} cached stores", tmajor=tm)
     for var, nm in ((0, "as built"), (4, "no DMA"), (5, "no barrier"), (6, "no DMA, no barrier")):
         fl = BIG | W4 | (var << 27) | NOEPI
         run(4096, 4096, 4096, 1, fl, f"w4 {nm}: 4096^3 no epilogue")
