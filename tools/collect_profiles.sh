@@ -8,22 +8,24 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 30 --warmup 5 2> $out/bench.err | tail -1 > $out/bench.json
-python $R/bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-peaks 2>> $out/bench.err | tail -1 > $out/bench_no_events.json
+# (the headline line as the driver runs it: 20 steps after 5, secondary workloads in config.secondary; the traced runs below pass --no-secondary --
+#  rocprofv3 follows the secondary workloads' child processes and would leave four result databases)
+python $R/bench.py --steps 20 --warmup 5 2> $out/bench.err | tail -1 > $out/bench.json
+python $R/bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-peaks --no-secondary 2>> $out/bench.err | tail -1 > $out/bench_no_events.json
 for c in gpt2-medium lenet5 gpt2-small-eq vit-b-lra; do
     python $R/bench.py --config $c --steps 30 --warmup 8 --no-cpu-baseline $( [ $c = vit-b-lra ] || echo --no-peaks ) 2>> $out/bench.err | tail -1 > $out/bench_$c.json
 done
-rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
+rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks --no-secondary > $out/bench_under_rocprof.json 2> $out/rocprof_stats.err
 db=$(find /tmp/p_stats -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db > $out/kernel_stats.md
 python $R/tools/rocpd_sequence.py $db accumulate_kernel -3 > $out/step_sequence.md
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks > /dev/null 2> $out/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks --no-secondary > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks --no-secondary > /dev/null 2> $out/pmc_write.err
 python $R/tools/pmc_traffic.py $(find /tmp/p_fetch -name "*.db" | head -1) $(find /tmp/p_write -name "*.db" | head -1) > $out/pmc_traffic.json
 ls -la $out
 # SQ counters, two passes of four (MFMA pipe busy + LDS conflicts; where the wave cycles went) -- counters only with --kernel-trace
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p_sq1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks > /dev/null 2> $out/pmc_sq1.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d /tmp/p_sq2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks > /dev/null 2> $out/pmc_sq2.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p_sq1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks --no-secondary > /dev/null 2> $out/pmc_sq1.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d /tmp/p_sq2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-apply-only --no-peaks --no-secondary > /dev/null 2> $out/pmc_sq2.err
 python $R/tools/pmc_sq.py $(find /tmp/p_sq1 -name "*.db" | head -1) > $out/pmc_sq_mfma.json
 python $R/tools/pmc_sq.py $(find /tmp/p_sq2 -name "*.db" | head -1) > $out/pmc_sq_waits.json
 # GPT-2-medium under rocprofv3 (the 8-GPU configuration's shapes on one GPU)
