@@ -6,7 +6,7 @@ import torch
 from psgd_torch_amd import _lib
 lib = _lib.lib()
 dev = "cuda:0"
-BIG, LOCK, NOEPI, NOMAIN = 1024, 2048, 256, 512
+BIG, NOEPI, NOMAIN = 1024, 256, 512
 
 
 def timed(fn, iters):
