@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 400    /* round 4: row shards (psgdk_plan_set_row_shard, psgdk_update_precond_begin / _finish, psgdk_balance_phase),
+#define PSGDK_VERSION 401    /* round 5 (401): row shards of the LRA preconditioner (psgdk_lra_set_row_shard, psgdk_lra_update_phase / _apply_phase / _phase_segments);
+                                round 4 (400): row shards (psgdk_plan_set_row_shard, psgdk_update_precond_begin / _finish, psgdk_balance_phase),
                                 psgdk_profile_read_calls; (300: test hooks moved to psgdk_test.h; 200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
 #define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
 
@@ -247,6 +248,28 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
 int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream);
 /* device word holding the sum of squares of the last psgdk_lra_precond_grad output (see psgdk_flat_apply_clipped) */
 int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr);
+
+/* ---- row shards of ONE LRA preconditioner (last row; new relative to the reference, whose LRA runs replicas only).
+ * U, V, d are cut by rows over the ranks: an object created with N = the shard's row count and declared by psgdk_lra_set_row_shard(row0)
+ * holds rows [row0, row0 + N) of the whole factors; g, v_noise and out are the shard's slices.  Every stage of psgd.py:994-1063 is row-local
+ * except its r x r / r-vector / scalar reductions, which the row passes accumulate in the fp32 scratch block at the start of the work
+ * buffer.  So the update runs as PSGDK_LRA_UPDATE_PHASES phases and the apply as PSGDK_LRA_APPLY_PHASES (the SAME launches, in the same
+ * order, that psgdk_lra_update_whiten / psgdk_lra_precond_grad issue back to back), and between two phases the caller reduces the words
+ * psgdk_lra_phase_segments names over the ranks -- op 0: sum, op 1: maximum -- and writes the result back on every rank (one collective
+ * per phase: 4 per update, the fifth phase ends with nothing to exchange; 3 per apply, the last one being the sum of out^2 the RMS clip
+ * reads through psgdk_lra_last_sumsq).  The Philox counters of the damping noise run over the WHOLE vector (row0 + local row), so the
+ * shards draw what one GPU would.  Tuned rank classes only (r <= 64): PSGDK_ERR_UNSUPPORTED above; on a declared shard the one-call
+ * forms return PSGDK_ERR_STATE.  psgd_torch_amd/lra_sharded.py drives this over torch.distributed. */
+#define PSGDK_LRA_UPDATE_PHASES 5
+#define PSGDK_LRA_APPLY_PHASES 3
+#define PSGDK_LRA_MAX_SEGMENTS 4
+int psgdk_lra_set_row_shard(psgdk_lra* lra, int64_t row0);
+int psgdk_lra_update_phase(psgdk_lra* lra, int phase, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                           float lr, float betaL, float damping, void* stream);
+int psgdk_lra_apply_phase(psgdk_lra* lra, int phase, const void* g, void* out, void* stream);
+/* kind 0: update, 1: apply.  word_offset[i] (fp32 words from the start of the work buffer), words[i], op[i] for i < *n_segments
+ * (<= PSGDK_LRA_MAX_SEGMENTS; 0 for the update's last phase). */
+int psgdk_lra_phase_segments(const psgdk_lra* lra, int kind, int phase, int* n_segments, int64_t* word_offset, int* words, int* op);
 
 /* ---- introspection (bench.py / tests; no reference counterpart): how the plan runs.  NLB_COOP: the norm lower bounds
  * (psgd.py:46-93) run as one cooperative launch per bound instead of start block + 4 grouped-GEMM products + scalars (set at

@@ -12,7 +12,7 @@ BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 400      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 401      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -103,6 +103,12 @@ SIGNATURES = {
     "psgdk_flat_apply_clipped": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
                                            C.c_float, C.c_float, C.c_void_p]),
     "psgdk_lra_last_sumsq": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "psgdk_lra_set_row_shard": (C.c_int, [C.c_void_p, C.c_int64]),
+    "psgdk_lra_update_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p]),
+    "psgdk_lra_apply_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psgdk_lra_phase_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int)]),
     "psgdk_fill_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
 }
 

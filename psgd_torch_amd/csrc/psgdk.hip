@@ -2245,6 +2245,8 @@ struct psgdk_lra {
     void* U = nullptr; void* V = nullptr; void* d = nullptr; float* Luvd = nullptr;
     unsigned char* work = nullptr;
     size_t sm_off = 0, v_off = 0, h_off = 0, qh_off = 0, iq_off = 0, diff_off = 0, y_off = 0, work_bytes = 0;
+    int64_t row0 = 0;          // psgdk_lra_set_row_shard: this object's rows are rows [row0, row0 + N) of a larger, row-sharded preconditioner
+    bool sharded = false;
 };
 
 extern "C" {
@@ -2354,18 +2356,21 @@ static int lra_apply_general(psgdk_lra* L, const void* g, void* out, hipStream_t
     return PSGDK_OK;
 }
 
-int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
-                            float lr, float betaL, float damping, void* stream) {
-    if (!lra || !g) return PSGDK_ERR_INVALID;
-    if (!lra->work) return PSGDK_ERR_STATE;
-    if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
-    psgdk_lra* L = lra;
-    hipStream_t st = (hipStream_t)stream;
+// The update as five phases and the apply as three: a phase ends where a reduction over ALL rows is complete in the scratch block `sm`
+// (the row passes add their partial sums / maxima there with atomics; the one-workgroup `small` kernels that consume them open the next
+// phase).  One GPU runs the phases back to back (psgdk_lra_update_whiten, psgdk_lra_precond_grad: the launches of rounds 1 - 4, in their
+// order); a row-sharded preconditioner (psgdk_lra_set_row_shard) reduces the phase's slots over the ranks in between.
+//   update phase 0: clear, Grams (psgd.py:1006)                      -> UTU, VTV, VTU                     (sum)
+//                1: small1 (rotation, :1007-1015), rotate             -> V^T (d h), U^T (v / d)            (sum)
+//                2: small2 (LU, first solve, :1020-1024), pass 3      -> a^T U, b^T U, a^T V, b^T V, |a|^2, |b|^2   (sum)
+//                3: small3 (second solve, :1025), pass 4              -> max |Ph h|, max |v invPv|         (max)
+//                4: small4 (Lipschitz constants, coefficients, :1031-1052), pass 5 (the rank-1 updates)
+//   apply phase 0: clear, V^T (d g);  1: y, U^T y;  2: out, sum of out^2      (sum each)
+static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                              float lr, float betaL, float damping, hipStream_t st) {
     float* sm = (float*)(L->work + L->sm_off);
     const int64_t N = L->N; const int r = L->r;
-    if (r > LRA_RMAX) return lra_update_general(L, g, v_noise, seed, offset, update_u, lr, betaL, damping, st);
     const int tpr = lra_tpr_of_rank(r), rm = 16 * tpr;
-    const unsigned gb = (unsigned)std::min<int64_t>((N + 255) / 256, 2048);
     unsigned gb1, gb2, gbr, shm1, shm2, shmr;
     lra_geometry(N, r, 1, 0, &gb1, &shm1); lra_geometry(N, r, 2, 0, &gb2, &shm2);
     lra_geometry(N, r, 2, 2u * rm * rm * 4u, &gbr, &shmr);                       // the rotation keeps M_u, M_v in LDS as well
@@ -2373,59 +2378,148 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
     // only the update's own slots: HSQ (||h||^2 of the last psgdk_lra_precond_grad, read by psgdk_flat_apply_clipped) and the apply's
     // reduction slots behind it survive an update that runs between precond_grad and the clipped parameter update
     // (update_preconditioner_first=False, psgd.py:1172-1183)
-    HIPCHK(hipMemsetAsync(sm, 0, (size_t)(tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ)) * 4, st));
+    if (phase == 0)
+        HIPCHK(hipMemsetAsync(sm, 0, (size_t)(tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ)) * 4, st));
     LRA_T(L, {
-        T* v = (T*)(L->work + L->v_off); T* h = (T*)(L->work + L->h_off); T* Qh = (T*)(L->work + L->qh_off);
-        T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
+        T* Qh = (T*)(L->work + L->qh_off); T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
         // (no preparation pass: v and h are rebuilt from g where they are used -- LraVH)
-        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset};
-        (void)v; (void)h; (void)gb;
-        if (r > 0) {
-            hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
-            if (shm_s1 > 64u * 1024u)
-                HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
-            hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
+        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset, L->row0};
+        switch (phase) {
+        case 0:
+            if (r > 0) hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
+            break;
+        case 1:
+            if (r > 0) {
+                if (shm_s1 > 64u * 1024u)
+                    HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
+                hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
+            }
+            if constexpr (TPR == 1) {
+                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
+            } else {      // wider rank classes: the rotation on the fp32 matrix cores
+                const int rows_m = LRA_ROWS / TPR;
+                const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
+                hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, vh, N, r, sm);
+            }
+            break;
+        case 2:
+            hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+            hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                               Qh, iq, N, r, sm);
+            break;
+        case 3:
+            hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+            hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+                               (const T*)Qh, (const T*)iq, diff, N, r, sm);
+            break;
+        default:
+            hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
+            hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+                               N, r, update_u ? 1 : 0, (const float*)sm);
+            break;
         }
-        if constexpr (TPR == 1) {
-            hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
-        } else {      // wider rank classes: the rotation on the fp32 matrix cores
-            const int rows_m = LRA_ROWS / TPR;
-            const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
-            hipLaunchKernelGGL((lra_rotate_mfma_kernel<T, TPR>), dim3(gm), dim3(LRA_THREADS), 0, st, U, V, (const T*)d, vh, N, r, sm);
-        }
-        hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
-                           Qh, iq, N, r, sm);
-        hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-        hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
-                           (const T*)Qh, (const T*)iq, diff, N, r, sm);
-        hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
-        hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
-                           N, r, update_u ? 1 : 0, (const float*)sm);
     });
     HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+static int lra_apply_phase_t(psgdk_lra* L, int phase, const void* g, void* out, hipStream_t st) {
+    float* sm = (float*)(L->work + L->sm_off);
+    unsigned gb1, shm1;
+    lra_geometry(L->N, L->r, 1, 0, &gb1, &shm1);
+    LRA_T(L, {
+        if (phase == 0) HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
+        T* y = (T*)(L->work + L->y_off);
+        hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+                           (const T*)g, y, (T*)out, L->N, L->r, phase, sm);
+    });
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+static int lra_update_args_ok(const psgdk_lra* lra, const void* g, float lr, float betaL, float damping) {
+    if (!lra || !g) return PSGDK_ERR_INVALID;
+    if (!lra->work) return PSGDK_ERR_STATE;
+    if (!(lr > 0.f) || !(betaL >= 0.f && betaL <= 1.f) || !(damping >= 0.f)) return PSGDK_ERR_INVALID;
+    return PSGDK_OK;
+}
+
+int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                            float lr, float betaL, float damping, void* stream) {
+    int rc = lra_update_args_ok(lra, g, lr, betaL, damping);
+    if (rc) return rc;
+    if (lra->sharded) return PSGDK_ERR_STATE;        // a row shard's reductions are incomplete without the exchanges: psgdk_lra_update_phase
+    hipStream_t st = (hipStream_t)stream;
+    if (lra->r > LRA_RMAX) return lra_update_general(lra, g, v_noise, seed, offset, update_u, lr, betaL, damping, st);
+    for (int phase = 0; phase < 5; ++phase)
+        if ((rc = lra_update_phase_t(lra, phase, g, v_noise, seed, offset, update_u, lr, betaL, damping, st))) return rc;
     return PSGDK_OK;
 }
 
 int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream) {
     if (!lra || !g || !out) return PSGDK_ERR_INVALID;
     if (!lra->work) return PSGDK_ERR_STATE;
-    psgdk_lra* L = lra;
+    if (lra->sharded) return PSGDK_ERR_STATE;
     hipStream_t st = (hipStream_t)stream;
-    float* sm = (float*)(L->work + L->sm_off);
-    if (L->r > LRA_RMAX) return lra_apply_general(L, g, out, st);
-    unsigned gb1, shm1;
-    lra_geometry(L->N, L->r, 1, 0, &gb1, &shm1);
-    LRA_T(L, {
-        HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
-        T* y = (T*)(L->work + L->y_off);
-        for (int stage = 0; stage < 3; ++stage) {
-            hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
-                               (const T*)g, y, (T*)out, L->N, L->r, stage, sm);
-        }
-    });
-    HIPCHK(hipGetLastError());
+    if (lra->r > LRA_RMAX) return lra_apply_general(lra, g, out, st);
+    for (int phase = 0; phase < 3; ++phase) {
+        const int rc = lra_apply_phase_t(lra, phase, g, out, st);
+        if (rc) return rc;
+    }
+    return PSGDK_OK;
+}
+
+// ---- row shards of one LRA preconditioner (last row) -----------------------------------------------------
+int psgdk_lra_set_row_shard(psgdk_lra* lra, int64_t row0) {
+    if (!lra || row0 < 0) return PSGDK_ERR_INVALID;
+    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;       // (the general-rank path keeps r x r matrices in global memory: not split into phases)
+    lra->row0 = row0; lra->sharded = true;
+    return PSGDK_OK;
+}
+
+int psgdk_lra_update_phase(psgdk_lra* lra, int phase, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u,
+                           float lr, float betaL, float damping, void* stream) {
+    const int rc = lra_update_args_ok(lra, g, lr, betaL, damping);
+    if (rc) return rc;
+    if (phase < 0 || phase >= PSGDK_LRA_UPDATE_PHASES) return PSGDK_ERR_INVALID;
+    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
+    return lra_update_phase_t(lra, phase, g, v_noise, seed, offset, update_u, lr, betaL, damping, (hipStream_t)stream);
+}
+
+int psgdk_lra_apply_phase(psgdk_lra* lra, int phase, const void* g, void* out, void* stream) {
+    if (!lra || !g || !out || phase < 0 || phase >= PSGDK_LRA_APPLY_PHASES) return PSGDK_ERR_INVALID;
+    if (!lra->work) return PSGDK_ERR_STATE;
+    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
+    return lra_apply_phase_t(lra, phase, g, out, (hipStream_t)stream);
+}
+
+// the slots of the scratch block (fp32 words, relative to the start of the work buffer) that the phase's row pass has accumulated and the
+// next phase reads: up to PSGDK_LRA_MAX_SEGMENTS runs of words, each summed (op 0) or maximised (op 1) over the shards
+int psgdk_lra_phase_segments(const psgdk_lra* lra, int kind, int phase, int* n_segments, int64_t* word_offset, int* words, int* op) {
+    if (!lra || !n_segments || !word_offset || !words || !op) return PSGDK_ERR_INVALID;
+    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
+    const int tpr = lra_tpr_of_rank(lra->r);
+    const int64_t base = (int64_t)(lra->sm_off / 4);
+    int n = 0;
+    auto seg = [&](int off, int cnt, int o) { word_offset[n] = base + off; words[n] = cnt; op[n] = o; ++n; };
+#define LRA_SEGS(TPR_)                                                                                                    \
+    { using C = LraCfg<TPR_>;                                                                                              \
+      if (kind == 0) {                                                                                                     \
+          if (phase == 0) seg(C::UTU, 3 * C::MS, 0);                                                                       \
+          else if (phase == 1) seg(C::VTX, 2 * C::RM, 0);                                                                  \
+          else if (phase == 2) { seg(C::ATU, 4 * C::RM, 0); seg(C::NA2, 2, 0); }                                           \
+          else if (phase == 3) seg(C::MAX1, 2, 1);                                                                         \
+          else if (phase != 4) return PSGDK_ERR_INVALID;                                                                   \
+      } else if (kind == 1) {                                                                                              \
+          if (phase == 0) seg(C::VTX2, C::RM, 0);                                                                          \
+          else if (phase == 1) seg(C::UTY, C::RM, 0);                                                                      \
+          else if (phase == 2) seg(C::HSQ, 1, 0);                                                                          \
+          else return PSGDK_ERR_INVALID;                                                                                   \
+      } else return PSGDK_ERR_INVALID; }
+    if (tpr == 1) LRA_SEGS(1) else if (tpr == 2) LRA_SEGS(2) else LRA_SEGS(4)
+#undef LRA_SEGS
+    *n_segments = n;
     return PSGDK_OK;
 }
 

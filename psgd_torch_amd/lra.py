@@ -77,6 +77,38 @@ class _LraEngine:
         L.check(self.lib.psgdk_lra_precond_grad(self.h, g.data_ptr(), out.data_ptr(), self._stream()), "lra_precond_grad")
         return out
 
+    # ---- the phase interface of a row shard (include/psgdk.h "row shards of ONE LRA preconditioner"; driven by lra_sharded.RowShardedLRA) ----
+    UPDATE_PHASES, APPLY_PHASES = 5, 3
+
+    def set_row_shard(self, row0: int):
+        L.check(self.lib.psgdk_lra_set_row_shard(self.h, int(row0)), "lra_set_row_shard")
+
+    @property
+    def scratch(self) -> torch.Tensor:
+        """The work buffer as fp32 words: the reduction slots psgdk_lra_phase_segments names live at its start."""
+        return self.work[: (self.work.numel() // 4) * 4].view(torch.float32)
+
+    def segments(self, kind: int, phase: int):
+        n = C.c_int()
+        off, cnt, op = (C.c_int64 * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+        L.check(self.lib.psgdk_lra_phase_segments(self.h, int(kind), int(phase), C.byref(n), off, cnt, op), "lra_phase_segments")
+        return [(int(off[i]), int(cnt[i]), int(op[i])) for i in range(n.value)]
+
+    @_on_device
+    def update_phase(self, phase, g, lr, betaL, damping, v_noise=None, seed=0, offset=0, update_u=True):
+        if phase == 0:
+            g = g.contiguous()
+            vn = v_noise.to(g.dtype).contiguous() if v_noise is not None else None
+            self._k = (g, vn)
+        g, vn = self._k
+        L.check(self.lib.psgdk_lra_update_phase(self.h, int(phase), g.data_ptr(), vn.data_ptr() if vn is not None else None, int(seed),
+                                                int(offset), int(bool(update_u)), float(lr), float(betaL), float(damping),
+                                                self._stream()), "lra_update_phase")
+
+    @_on_device
+    def apply_phase(self, phase, g, out):
+        L.check(self.lib.psgdk_lra_apply_phase(self.h, int(phase), g.data_ptr(), out.data_ptr(), self._stream()), "lra_apply_phase")
+
 
 def _engine_for(UVd, Luvd, rebind: bool = True) -> _LraEngine:
     """The reference passes (UVd, Luvd) lists of tensors around; the engine needs the three L scalars contiguous, so the
@@ -190,7 +222,8 @@ class LRAWhiten:
 
     def __init__(self, params_with_grad, rank_of_approximation: int = 10, preconditioner_init_scale: Optional[float] = None,
                  lr_params=0.001, lr_preconditioner=0.1, betaL=0.9, damping=1e-9, momentum=0.0, grad_clip_max_amps=(2.0, 10.0),
-                 preconditioner_update_probability=1.0, update_preconditioner_first=True, whiten_grad=True):
+                 preconditioner_update_probability=1.0, update_preconditioner_first=True, whiten_grad=True, *,
+                 shard_rows: bool = False, process_group=None, seed: int = 0):
         # the reference's mutable members (psgd.py:1094-1103)
         self.lr_params, self.lr_preconditioner, self.betaL, self.damping = lr_params, lr_preconditioner, betaL, damping
         self.momentum = momentum if (0 < momentum < 1) else 0.0
@@ -207,28 +240,76 @@ class LRAWhiten:
             raise NotImplementedError("the HIP LRA kernels hold rank <= 1024 (psgdk_lra_create: PSGDK_ERR_UNSUPPORTED); ranks above 64 take "
                                       "the general path")
         dev, dt = self._vec.device, p0.dtype
+        # shard_rows=True under an initialised process group: U, V, d are cut by rows over the ranks (lra_sharded.py; SURVEY 8e, last row).
+        # Gradients and parameters stay whole on every rank (the DDP surface); every rank must pass the same `seed`: the gates, the
+        # U-or-V coin and the Philox seed of the damping noise come from a private generator, not from torch's global one.
+        import torch.distributed as dist
+        self._shard = None
+        world = dist.get_world_size(process_group) if (shard_rows and dist.is_available() and dist.is_initialized()) else 1
+        if shard_rows and world > 1:
+            from . import lra_sharded
+            rank = dist.get_rank(process_group)
+            row0, rows = lra_sharded.shard_rows(N, world, rank)
+            every = [lra_sharded.shard_rows(N, world, k)[1] for k in range(world)]
+            if min(every) <= r:
+                raise ValueError(f"shard_rows: {N} rows over {world} ranks leaves a rank with {min(every)} rows for rank-{r} factors; "
+                                 "use fewer ranks or replicas")
+            if r > 64:
+                raise NotImplementedError("shard_rows: the phased engine covers the tuned rank classes (r <= 64)")
+            self._shard = dict(world=world, rank=rank, row0=row0, rows=rows, group=process_group, driver=None)
+            self._gen = torch.Generator().manual_seed(int(seed))
+        n_local = self._shard["rows"] if self._shard else N
 
-        def unit_scaled():                                                   # psgd.py:1115-1118
-            x = torch.randn(N, r, dtype=dt, device=dev)
-            return x * (0.1 ** 0.5 / torch.linalg.vector_norm(x)) if r else x
-        self._UVd = [unit_scaled(), unit_scaled()]
+        def unit_scaled(k):                                                  # psgd.py:1115-1118
+            if self._shard is None:
+                x = torch.randn(N, r, dtype=dt, device=dev)
+                return x * (0.1 ** 0.5 / torch.linalg.vector_norm(x)) if r else x
+            g_ = torch.Generator(device=dev).manual_seed(int(seed) * 1000003 + 2 * self._shard["rank"] + k)       # this rank's rows of one N x r draw
+            x = torch.randn(n_local, r, dtype=dt, device=dev, generator=g_)
+            ss = (x.float() ** 2).sum().reshape(1)
+            tot = lra_sharded.RowShardedLRA._sum_over_ranks(ss, world, process_group)
+            return x * (0.1 ** 0.5 / tot.sqrt()).to(dt) if r else x
+        self._UVd = [unit_scaled(0), unit_scaled(1)]
         self._init_scale = preconditioner_init_scale
         if preconditioner_init_scale is None:
             print("FYI: Will set the preconditioner initial scale on the fly. Recommend to set it manually.")
         else:
-            self._UVd.append(torch.full((N, 1), float(preconditioner_init_scale), dtype=dt, device=dev))
+            self._UVd.append(torch.full((n_local, 1), float(preconditioner_init_scale), dtype=dt, device=dev))
         self._Luvd = [torch.zeros([], dtype=torch.float32, device=dev) for _ in range(3)]
         self._m, self._counter_m = None, 0
         self._whiten_grad = whiten_grad
         if not whiten_grad:
             assert self.momentum > 0, "Cannot whiten momentum if the momentum setting is invalid."
         # hooks for tests that replay the reference's recorded draws
-        self._uniform = lambda: float(torch.rand([]))
+        self._uniform = (lambda: float(torch.rand([]))) if self._shard is None else (lambda: float(torch.rand([], generator=self._gen)))
         self._v_noise = None
 
     def _update(self, target):
+        if self._shard is not None:
+            sh = self._shard
+            coin = self._uniform()
+            seed = int(torch.randint(0, 2 ** 62, (), generator=self._gen).item())
+            vn = self._v_noise() if self._v_noise is not None else None
+            loc = slice(sh["row0"], sh["row0"] + sh["rows"])
+            self._driver().update_whiten(target[loc], lr=self.lr_preconditioner, betaL=self.betaL, damping=self.damping,
+                                         v_noise=vn[loc] if vn is not None else None, seed=seed, offset=0, update_u=coin < 0.5)
+            return
         update_precond_lra_whiten(self._UVd, self._Luvd, target, lr=self.lr_preconditioner, betaL=self.betaL, damping=self.damping,
                                   v_noise=self._v_noise() if self._v_noise is not None else None, coin=self._uniform())
+
+    def _driver(self):
+        """The row shard's engine + exchange driver, made when d exists (the on-the-fly scale needs the first gradient)."""
+        sh = self._shard
+        if sh["driver"] is None:
+            from . import lra_sharded
+            L3 = torch.stack([x.detach().to(torch.float32).reshape(()) for x in self._Luvd]).to(self._UVd[2].device)
+            self._Luvd = [L3[i] for i in range(3)]
+            eng = _LraEngine(self._UVd, L3)
+            eng.set_row_shard(sh["row0"])
+            self._UVd[2]._psgdk_lra = eng
+            eng.key = None
+            sh["driver"] = lra_sharded.RowShardedLRA(eng, sh["group"])
+        return sh["driver"]
 
     @torch.no_grad()
     def step(self, closure):
@@ -249,7 +330,8 @@ class LRAWhiten:
         vec.gather(grads, m=self._m, beta=beta, want_g4=need_d)              # g (and m) as one N-vector; sum g^4 if d is unset
         if need_d:                                                           # psgd.py:1144-1145, on the device
             scale = (vec.sum_g4 / vec.N + self.damping ** 4) ** (-1 / 8)
-            self._UVd.append(scale.to(vec.g.dtype) * torch.ones_like(vec.g))
+            self._UVd.append(scale.to(vec.g.dtype) * (torch.ones_like(vec.g) if self._shard is None else
+                                                      torch.ones(self._shard["rows"], 1, dtype=vec.g.dtype, device=vec.g.device)))
         if self._uniform() < self.preconditioner_update_probability:         # psgd.py:1157-1160
             first, last = self.update_preconditioner_first, not self.update_preconditioner_first
         else:
@@ -257,6 +339,18 @@ class LRAWhiten:
         target = vec.g if self._whiten_grad else self._m
         if first:
             self._update(target)
+        if self._shard is not None:                                          # this rank's rows of h, then the whole h on every rank
+            from . import lra_sharded
+            sh = self._shard
+            src = self._m if use_m else vec.g
+            h_loc = self._driver().precond_grad(src[sh["row0"]:sh["row0"] + sh["rows"]])
+            h = lra_sharded.all_gather_rows(h_loc, vec.N, sh["world"], sh["rank"], sh["group"])
+            eng = self._driver().engine        # (its sum-of-squares word holds the sum over ALL rows after the apply's last exchange)
+            max_avg_amp, max_element_amp = self.grad_clip_max_amps
+            vec.apply_clipped(self._params_with_grad, h, self.lr_params, eng.last_sumsq_ptr(), max_avg_amp, max_element_amp)
+            if last:
+                self._update(target)
+            return out
         h = precond_grad_lra(self._UVd, self._m if use_m else vec.g)         # psgd.py:1168-1171
         # The clipped parameter update goes BEFORE a trailing preconditioner update: it reads ||h||^2 from a device word of the
         # engine that produced h, and on the first step a trailing update re-binds a fresh engine (own scratch block).  The
