@@ -30,6 +30,12 @@ class _LraEngine:
         for t in (U, V, d):
             if not t.is_contiguous():
                 raise L.PsgdkError(L.PSGDK_ERR_INVALID, "U, V, d must be contiguous")
+        if self.r > 256:
+            #  the general path (64 < r <= 1024) does its r x r work -- E @ E, the pivoted LU, two solves -- in ONE workgroup:
+            # O(r^3) near-serial multiply-adds per update (~1e9 at r = 1024).  Correct, covered by goldens at 96 and 130 and by fuzz to 200; slow.
+            import warnings
+            warnings.warn(f"LRA rank {self.r}: above 256 the r x r stages of an update run in a single workgroup (O(r^3) per update); "
+                          "expect the update to be dominated by them", RuntimeWarning, stacklevel=3)
         self.h = C.c_void_p()
         L.check(self.lib.psgdk_lra_create(C.byref(self.h), self.N, self.r, L.dtype_code(d.dtype)), "lra_create")
         wb = C.c_size_t()
