@@ -196,7 +196,7 @@ def bench_lra(args):
         scratch = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
         scratch.random_(0, 255)
         pk = (C.c_float * 4)()
-        _lib.check(_lib.lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
+        _lib.check(_lib.probe_lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
         del scratch
         peaks = {"hbm_copy_gbs": pk[2], "hbm_read_gbs": pk[3],
                  "what": "streaming 16-byte copy (read + write) / read of 1 GiB, best of 3, measured in this process after the timed region"}
@@ -487,7 +487,10 @@ def main():
     gc.collect()
     gc_before = [g["collections"] for g in gc.get_stats()]
     gc.callbacks.append(gc_watch)
-    for i in range(1, args.warmup):
+    # step 0 built the engines; at least one more untimed step follows the collector run, so that the timed region never starts on an
+    # idle GPU and never repeats a step index (with --warmup 0 / 1 that is one / no step more than asked: reported as warmup_steps_run)
+    n_warm = max(args.warmup, 2)
+    for i in range(1, n_warm):
         one_step(i)
     # the grouped-GEMM launches of every `sample`-th timed step carry an event pair each (for the roofline object).  The events ride on
     # the launches' own dispatch packets (hipExtLaunchKernelGGL) and no longer fence the stream; the four hot-path calls' own pairs do,
@@ -510,7 +513,7 @@ def main():
         sampled.append(on)
         for e in engines:
             e.profile_enable(on, calls=on and prof_steps == 1)      # (the calls' own event pairs fence the stream: one sampled step carries them)
-        one_step(args.warmup + i)
+        one_step(n_warm + i)
         step_ev[i + 1].record()
     host_dt = time.perf_counter() - t0          # host enqueue time (no sync inside): shows whether the host keeps ahead
     fence()
@@ -664,10 +667,10 @@ def main():
         scratch = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
         scratch.random_(0, 255)
         pk = (C.c_float * 4)()
-        _lib.check(_lib.lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
+        _lib.check(_lib.probe_lib().psgdk_test_peaks(pk, scratch.data_ptr(), scratch.numel(), _lib.current_stream()), "test_peaks")
         del scratch
         clk = C.c_float()
-        _lib.check(_lib.lib().psgdk_test_clock(C.byref(clk), _lib.current_stream()), "test_clock")
+        _lib.check(_lib.probe_lib().psgdk_test_clock(C.byref(clk), _lib.current_stream()), "test_clock")
         out["config"]["shader_clock_mhz_under_mfma_load"] = clk.value
         r = out["roofline"]
         r["peak_measured"] = {"mfma_16x16x32_bf16_tflops": pk[0], "mfma_32x32x16_bf16_tflops": pk[1], "hbm_copy_gbs": pk[2],

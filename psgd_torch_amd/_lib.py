@@ -114,10 +114,9 @@ SIGNATURES = {
 
 # include/psgdk_test.h: kernel-level test / benchmark hooks (same library, not part of the drop-in ABI)
 TEST_SIGNATURES = {
+    "psgdk_test_ew_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_test_dump_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
-    "psgdk_test_peaks": (C.c_int, [C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "psgdk_test_clock": (C.c_int, [C.POINTER(C.c_float), C.c_void_p]),
     "psgdk_test_nlb_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "psgdk_test_nlb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_test_gemm_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -133,6 +132,29 @@ TEST_SIGNATURES = {
     "psgdk_test_trsm_right": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
 }
+
+
+# libpsgdk_probe.so (csrc/psgdk_probe.hip): the chip's measured ceilings for bench.py -- a tool library, not in the product
+PROBE_LIB_PATH = os.path.join(_HERE, "libpsgdk_probe.so")
+PROBE_SIGNATURES = {
+    "psgdk_test_peaks": (C.c_int, [C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "psgdk_test_clock": (C.c_int, [C.POINTER(C.c_float), C.c_void_p]),
+}
+_probe = None
+
+
+def probe_lib():
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise PsgdkError(-1, f"{PROBE_LIB_PATH} is missing: build it with `python -m psgd_torch_amd.build`")
+        import torch  # noqa: F401
+        L = C.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in PROBE_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _probe = L
+    return _probe
 
 
 def lib():

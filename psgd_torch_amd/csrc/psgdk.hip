@@ -5,8 +5,6 @@
 // over ALL tensors (the reference issues ~100 ATen launches per tensor), with every scalar kept on the device.
 #include <hip/hip_ext.h>
 #include "host_util.hiph"
-#include "gemm_w4.hiph"
-#include "gemm_w4p.hiph"
 #include "descs.hiph"
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
@@ -14,7 +12,6 @@
 #include "kernels_lra_gen.hiph"
 #include "kernels_gen.hiph"
 #include "kernels_eq.hiph"
-#include "kernels_probe.hiph"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -31,9 +28,6 @@ struct Stage {                       // one grouped GEMM launch
     bool one_per_tile = false;       // tests / experiments: the staggered-phase kernel with one workgroup per tile (not persistent)
     bool ext = false;                // problems use GemmProblem::skip / GF_PROCR3 (PRO4P): the EXT instantiation, small tiling
     bool ksplit = false;             // small launches: 64 x 64 tiles, K split over the four waves (gemm_nt_ks_kernel)
-    bool w4 = false;                 // (with big) the four-wave 256x256 kernel of gemm_w4.hiph: bf16 "fast" problems with K >= 128 only
-    int w4_var = 0;                  // timing experiments (test hooks): parts of its main loop / epilogue left out
-    bool w4p = false;                // (with big) the ping-pong four-wave kernel of gemm_w4p.hiph (256 x 128 tiles): gemm_w4p_takes() problems only
 };
 
 struct FactorRef { int kind; int idx; };   // idx into dd (diag/scalar) or dn (dense)
@@ -85,9 +79,21 @@ struct psgdk_plan {
     volatile unsigned* h_err = nullptr; unsigned* d_err = nullptr;
     int64_t nlb_fallbacks = 0;        // how often a timeout moved this plan to the multi-launch route (0 or 1)
     bool nlb_unfused = false;        // PSGDK_NLB_FUSED=0 at plan creation: keep the multi-launch route (tests compare the two)
+    int ew_dbg = 0;                  // psgdk_test_ew_mode
+    bool no_fuse = false;            // psgdk_test_fuse_mode(0): psgdk_precond_grad_apply takes the two-pass route (A/B runs, parity tests)
     bool p_valid = false;
     bool x_valid = false, x_explicit = false; int x_source = 0; float x_damping = 0.f; uint64_t x_seed = 0, x_offset = 0;
     Stage g_P, g_upd_a, g_upd_b, g_gram, g_qupd, g_rq, g_rrq, g_app_a[2], g_app_b, g_nlb[2][4];
+    // psgdk_precond_grad_apply (round 6): the apply's last product with the parameter update fused into its epilogue (GemmProblem::upd_p).
+    // The stages are copies of g_app_a[src] / g_app_b with the callers' parameter pointers in them, rebuilt when those change (fused_key).
+    Stage f_app_a, f_app_b;
+    std::vector<int> app_a_tensor, app_b_tensor;     // per problem of g_app_a[.] / g_app_b: its tensor
+    std::vector<const void*> fused_key;              // [params..., (void*)src] the fused stages were built for; empty = not built
+    bool fused_any = false;                          // at least one tensor takes the fused epilogue (otherwise the call runs unfused)
+    bool h_fused = false;                            // the work arena's h was produced by the fused stages: fused tensors' h is in LOGICAL
+                                                     // orientation and already applied -- read / export / apply_update refuse it
+    EwTile* d_tiles_rest = nullptr; unsigned n_tiles_rest = 0;      // streaming tiles of the tensors the fused epilogue does not cover
+    FixDesc* d_fix = nullptr; unsigned n_fix = 0;
     std::vector<int> split_dense;                    // dense factors whose Gram is split-K
     // row shards (psgdk_plan_set_row_shard): tensors of this plan that are row blocks of a larger, row-sharded tensor.  Their dense
     // factor is replicated on the `members` owners of the blocks and fitted to the WHOLE tensor: the members' partial mode Grams
@@ -119,7 +125,7 @@ struct psgdk_plan {
     size_t prof_used = 0, prof_call_used = 0;
 
     std::vector<Stage*> all_stages() {
-        std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b};
+        std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b, &f_app_a, &f_app_b};
         for (int c = 0; c < 2; ++c) for (int p = 0; p < 4; ++p) v.push_back(&g_nlb[c][p]);
         for (Stage* e : {&e_a1, &e_a2, &e_g1, &e_g2, &e_qupd, &v_qeq, &v_quad2, &v_qep_u, &v_qep_t1, &v_qep_t2, &v_pro_rq, &v_pro_rrq, &v_pro_rrrq}) v.push_back(e);
         return v;
@@ -133,7 +139,7 @@ struct psgdk_plan {
         for (auto& e : prof_call_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (Stage* s : all_stages()) { fr(s->d_probs); fr(s->d_tiles); }
         for (int k = 0; k < 2; ++k) { fr(d_trsm[k]); fr(d_trsm_tiles[k]); }
-        fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_ts);
+        fr(d_uinv); fr(d_nlb_jobs); fr(d_nlb_ts); fr(d_tiles_rest); fr(d_fix);
         if (h_err) (void)hipHostFree((void*)h_err);
     }
 };
@@ -151,7 +157,6 @@ int upload(X** dst, const std::vector<X>& v) {
 
 int finish_stage(Stage& s) {
     TileTableBuilder tb;
-    tb.w4p = s.big && s.w4p;
     tb.bm = s.big ? GEMM_BIG_BM : (s.ksplit ? 64 : GEMM_BM);
     tb.bn = s.big ? GEMM_BIG_BN : (s.ksplit ? 64 : GEMM_BN);
     for (size_t i = 0; i < s.probs.size(); ++i) tb.add_problem((int)i, s.probs[i]);
@@ -189,32 +194,15 @@ static unsigned persistent_grid(unsigned n_tiles) {
         else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__);                                    \
     } while (0)
 template <typename T>
-void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const GemmUpdArgs upd = GemmUpdArgs{0.f, 1.f, 0.f, 0}) {
     if (!s.n_tiles) return;
-    if (s.big && s.w4p && sizeof(T) == 2) {
-        const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
-        switch (s.w4_var) {
-            case 4: PSGDK_LAUNCH(gemm_nt_w4p_kernel<5>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // timing: no epilogue, no DMA in the loop
-            case 7: PSGDK_LAUNCH(gemm_nt_w4p_kernel<4>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // timing: no epilogue
-            default: PSGDK_LAUNCH(gemm_nt_w4p_kernel<0>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
-        }
-    }
-    else if (s.big && s.w4 && sizeof(T) == 2) {
-        const dim3 g(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles));
-        switch (s.w4_var) {
-            case 4: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 1>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no DMA in the loop
-            case 5: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 2>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // no barrier
-            case 6: PSGDK_LAUNCH((gemm_nt_w4_kernel<4, 3>), g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;      // neither
-            default: PSGDK_LAUNCH(gemm_nt_w4_kernel<4>, g, dim3(256), s.d_probs, s.d_tiles, (int)s.n_tiles); break;
-        }
-    }
-    else if (s.big) PSGDK_LAUNCH(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512),
-                                 s.d_probs, s.d_tiles, (int)s.n_tiles);
+    if (s.big) PSGDK_LAUNCH(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512),
+                                 s.d_probs, s.d_tiles, (int)s.n_tiles, upd);
     else if (s.ksplit) PSGDK_LAUNCH(gemm_nt_ks_kernel<T>, dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles);
-    else if (s.ext) PSGDK_LAUNCH((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles);
-    else PSGDK_LAUNCH((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles);
+    else if (s.ext) PSGDK_LAUNCH((gemm_nt_kernel<T, true>), dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles, upd);
+    else PSGDK_LAUNCH((gemm_nt_kernel<T, false>), dim3(s.n_tiles), dim3(256), s.d_probs, s.d_tiles, upd);
 }
-void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
+void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st, const GemmUpdArgs* upd = nullptr) {
     if (!s.n_tiles) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->prof) {
@@ -226,7 +214,8 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st) {
         e0 = p->prof_ev[p->prof_used].first; e1 = p->prof_ev[p->prof_used].second;
         ++p->prof_used;
     }
-    if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st, e0, e1); else launch_stage_t<float>(s, st, e0, e1);
+    const GemmUpdArgs u = upd ? *upd : GemmUpdArgs{0.f, 1.f, 0.f, 0};
+    if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st, e0, e1, u); else launch_stage_t<float>(s, st, e0, e1, u);
 }
 
 // profiling (psgdk_profile_enable): an event pair around one hot-path call -- recorded on entry and when the call returns
@@ -601,6 +590,45 @@ int psgdk_plan_ema_view(const psgdk_plan* plan, int t, size_t* offset, int64_t* 
 
 static int nlb_plan_coop(psgdk_plan* P);
 
+    // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least three full rounds of its tiles (one
+    // workgroup per CU; 560 tiles = 2.19 rounds cost three, and the 128 x 128 kernel's finer tiles then fill the chip
+    // better: -2.4 % of the GPT-2-small step with the threshold at 768 instead of 512).  The subspace iteration
+    // (M = 64) and the EQ Grams / update stay on the small tiling; EQ's A = (kron Q) Hvp is a full-size product like upd_a.
+    // Both tilings accumulate K in the same order: same bits.
+static void decide_tiling(psgdk_plan* P, Stage* s) {
+    {
+        int64_t nb = 0, nb_f2 = 0;
+        for (const GemmProblem& g : s->probs) {
+            const int64_t tm = (g.M + GEMM_BIG_BM - 1) / GEMM_BIG_BM, tn = (g.N + GEMM_BIG_BN - 1) / GEMM_BIG_BN;
+            const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+            const int64_t nt = ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+            nb += nt;
+            if (P->dtype == PSGDK_BF16 && gemm_is_fused2_problem<bf16_t>(g)) nb_f2 += nt;
+        }
+        s->big = nb >= big_min_tiles();
+        // two-output problems with a fused update (Q', R Q, the symmetric Grams): only the 128 x 128 kernel has the register-
+        // resident epilogue for them (in the 256 x 256 one it spills); it wins there although its main loop is slower --
+        // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
+        // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
+        if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
+        // small launches: few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
+        s->ksplit = false;
+        if (!s->big && !s->ext && !s->probs.empty()) {
+            const int bk = P->dtype == PSGDK_BF16 ? 64 : 32;
+            int64_t n128 = 0;
+            bool ok = true;
+            for (const GemmProblem& g : s->probs) {
+                const int64_t tm = (g.M + GEMM_BM - 1) / GEMM_BM, tn = (g.N + GEMM_BN - 1) / GEMM_BN;
+                const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+                n128 += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
+                ok = ok && g.M % 64 == 0 && g.N % 64 == 0 && g.K % bk == 0 && g.K >= bk &&
+                     (!(g.flags & GF_SPLITK) || g.kchunk % bk == 0);
+            }
+            s->ksplit = ok && n128 <= kKsplitMaxTiles;
+        }
+    }
+}
+
 int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
     if (!plan || !state_arena || !work_arena) return PSGDK_ERR_INVALID;
     if (((uintptr_t)state_arena & 255) || ((uintptr_t)work_arena & 255)) return PSGDK_ERR_INVALID;
@@ -648,6 +676,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
 
     // ---- grouped GEMM stages (absolute pointers, so built at bind time) ----
     for (Stage* s : P->all_stages()) s->probs.clear();
+    P->app_a_tensor.clear(); P->app_b_tensor.clear();
     P->split_dense.clear();
     P->gram_prob.clear();
     float* hsumsq = (float*)(W + P->hsumsq_off);
@@ -754,6 +783,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 a.C = W + D.h_off; a.ldc = D.Cp; a.sumsq = hsumsq + t;
                 P->g_app_a[src].probs.push_back(a);
             }
+            P->app_a_tensor.push_back(t);
         } else {
             const DenseDesc& Fr = P->dn[D.row_dense];
             GemmProblem u = g; u.A = W + D.x_off; u.Ct = W + D.tt_off; u.ldct = D.Rp; u.flags |= GF_TMAJOR;
@@ -763,6 +793,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
                 a.Ct = W + D.tt_off; a.ldct = D.Rp; a.flags |= GF_TMAJOR;
                 P->g_app_a[src].probs.push_back(a);
             }
+            P->app_a_tensor.push_back(t);
             // second product: P_row * T, via T^T as the K-contiguous B operand
             GemmProblem b{};
             b.A = W + Fr.p_off; b.B = W + D.tt_off; b.M = D.Rp; b.N = D.Cp; b.K = D.Rp; b.lda = Fr.dp; b.ldb = D.Rp; b.alpha = 1.f;
@@ -770,6 +801,7 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
             P->g_upd_b.probs.push_back(ub);
             GemmProblem ab = b; ab.C = W + D.h_off; ab.ldc = D.Cp; ab.sumsq = hsumsq + t;
             P->g_app_b.probs.push_back(ab);
+            P->app_b_tensor.push_back(t);
         }
     }
     if (P->geometry == PSGDK_GEOM_QEQ || P->geometry == PSGDK_GEOM_QUAD || P->geometry == PSGDK_GEOM_QUAD4P)
@@ -902,60 +934,9 @@ int psgdk_plan_bind(psgdk_plan* plan, void* state_arena, void* work_arena) {
         P->n_uinv = (unsigned)uj.size();
         if ((rc = upload(&P->d_uinv, uj))) return rc;
     }
-    // tiling per stage: the 256 x 256 kernel pays off once a launch holds at least three full rounds of its tiles (one
-    // workgroup per CU; 560 tiles = 2.19 rounds cost three, and the 128 x 128 kernel's finer tiles then fill the chip
-    // better: -2.4 % of the GPT-2-small step with the threshold at 768 instead of 512).  The subspace iteration
-    // (M = 64) and the EQ Grams / update stay on the small tiling; EQ's A = (kron Q) Hvp is a full-size product like upd_a.
-    // Both tilings accumulate K in the same order: same bits.
     for (Stage* s : {&P->g_P, &P->g_upd_a, &P->g_upd_b, &P->g_gram, &P->g_qupd, &P->g_rq, &P->g_rrq, &P->g_app_a[0], &P->g_app_a[1],
-                     &P->g_app_b, &P->e_a1, &P->e_a2}) {
-        int64_t nb = 0, nb_f2 = 0;
-        for (const GemmProblem& g : s->probs) {
-            const int64_t tm = (g.M + GEMM_BIG_BM - 1) / GEMM_BIG_BM, tn = (g.N + GEMM_BIG_BN - 1) / GEMM_BIG_BN;
-            const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
-            const int64_t nt = ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
-            nb += nt;
-            if (P->dtype == PSGDK_BF16 && gemm_is_fused2_problem<bf16_t>(g)) nb_f2 += nt;
-        }
-        s->big = nb >= big_min_tiles();
-        // two-output problems with a fused update (Q', R Q, the symmetric Grams): only the 128 x 128 kernel has the register-
-        // resident epilogue for them (in the 256 x 256 one it spills); it wins there although its main loop is slower --
-        // GPT-2-medium (123 x 1024^3): Q' 446 -> 406 us, R Q 570 -> 429, mode Grams 531 -> 482 (profiles/r02_experiments).
-        // (PSGDK_BIG_MIN_TILES set: the tests want the big tiling wherever it can run)
-        if (s->big && s != &P->g_P && !getenv("PSGDK_BIG_MIN_TILES") && 2 * nb_f2 >= nb) s->big = false;     // (P = Q^T Q: 183 vs 197)
-        // The two four-wave 256 x 256 kernels of round 5 (accumulators in named AGPRs) can take a big stage whose problems are all "fast"
-        // bf16 problems -- the two full-size products of a step -- but only on request: inside the GPT-2-small step the plain one
-        // (gemm_w4.hiph, PSGDK_W4=1; main loop 13 % faster in isolation) measured EQUAL to the eight-wave kernel, the ping-pong one
-        // (gemm_w4p.hiph, PSGDK_W4P=1; epilogue of tile t - 1 interleaved with the main loop of tile t) 8 - 10 % BEHIND it.
-        s->w4 = false; s->w4p = false;
-        if (s->big && P->dtype == PSGDK_BF16) {
-            const char* e = getenv("PSGDK_W4P");
-            bool ok = e && atoi(e) != 0;
-            for (const GemmProblem& g : s->probs) ok = ok && gemm_w4p_takes(g);
-            s->w4p = ok;
-        }
-        if (s->big && P->dtype == PSGDK_BF16 && !s->w4p) {
-            const char* e = getenv("PSGDK_W4");
-            bool ok = e && atoi(e) != 0;
-            for (const GemmProblem& g : s->probs) ok = ok && gemm_w4_takes(g);
-            s->w4 = ok;
-        }
-        // small launches: few 128 x 128 tiles in the whole launch -> 64 x 64 tiles, K split over the waves
-        s->ksplit = false;
-        if (!s->big && !s->ext && !s->probs.empty()) {
-            const int bk = P->dtype == PSGDK_BF16 ? 64 : 32;
-            int64_t n128 = 0;
-            bool ok = true;
-            for (const GemmProblem& g : s->probs) {
-                const int64_t tm = (g.M + GEMM_BM - 1) / GEMM_BM, tn = (g.N + GEMM_BN - 1) / GEMM_BN;
-                const int64_t nks = (g.flags & GF_SPLITK) ? (g.K + g.kchunk - 1) / g.kchunk : 1;
-                n128 += ((g.flags & GF_SYM) ? tm * (tm + 1) / 2 : tm * tn) * nks;
-                ok = ok && g.M % 64 == 0 && g.N % 64 == 0 && g.K % bk == 0 && g.K >= bk &&
-                     (!(g.flags & GF_SPLITK) || g.kchunk % bk == 0);
-            }
-            s->ksplit = ok && n128 <= kKsplitMaxTiles;
-        }
-    }
+                     &P->g_app_b, &P->e_a1, &P->e_a2}) decide_tiling(P, s);
+    P->fused_key.clear();      // the fused-update stages (psgdk_precond_grad_apply) are rebuilt from the new tables at their next call
     for (Stage* s : P->all_stages())
         if ((rc = finish_stage(*s))) return rc;
     return PSGDK_OK;
@@ -1057,11 +1038,10 @@ int psgdk_accumulate(psgdk_plan* plan, const void* const* grads, int grad_dtype,
         }
         do_x = 1; x_from_grad = damp->source == PSGDK_SRC_GRAD; damping = damp->damping; seed = damp->seed; offset = damp->offset;
     }
-    // PSGDK_EW_DBG (measurement switch, tools/ew_bench.py / ew_check.py): 1 = damped input without the noise (the pass's HBM floor; wrong
+    // psgdk_test_ew_mode (test hook, tools/ew_bench.py / ew_check.py): 1 = damped input without the noise (the pass's HBM floor; wrong
     // results), 2 = the general path for every tile (same results as the compile-time-resolved path, bit for bit)
-    static const int ew_dbg = getenv("PSGDK_EW_DBG") ? atoi(getenv("PSGDK_EW_DBG")) : 0;
-    if (ew_dbg & 1) do_x |= do_x << 1;
-    if (ew_dbg & 2) do_x |= do_x << 2;
+    if (plan->ew_dbg & 1) do_x |= do_x << 1;
+    if (plan->ew_dbg & 2) do_x |= do_x << 2;
     DISPATCH_T(plan, hipLaunchKernelGGL(accumulate_kernel<T>, dim3(plan->n_tiles_all), dim3(256), 0, st, plan->d_td,
                                         plan->d_tiles_all, (const void* const*)d_grads, (const void* const*)d_params,
                                         plan->state, plan->work, grad_dtype, param_dtype, coupled_wd, beta, plan->use_momentum, keep,
@@ -1626,6 +1606,7 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream) {
     int rc;
     if (!P->hsq_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
     P->hsq_clean = false;
+    P->h_fused = false;
     if ((rc = ensure_P(P, st))) return rc;
     launch_stage(P, P->g_app_a[source], st);
     launch_stage(P, P->g_app_b, st);
@@ -1648,6 +1629,7 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
                        float max_avg_amp, float max_elem_amp, void* stream) {
     if (!plan || !params || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
+    if (plan->h_fused) return PSGDK_ERR_STATE;      // the last h was consumed by psgdk_precond_grad_apply (fused tensors: applied, logical orientation)
     if (!(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
     for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
     ProfCall prof_call(plan, stream);
@@ -1659,6 +1641,112 @@ int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, f
                                         plan->d_tiles_all,
                                         (void* const*)d_params, param_dtype, plan->work,
                                         (const float*)(plan->work + plan->hsumsq_off), 0, 1, lr, decoupled_wd, max_avg_amp, max_elem_amp, (void*)nullptr));
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+// precond_grad + apply_update in one call, with the parameter update FUSED into the epilogue of the apply's last product wherever a
+// tensor allows it (..._ddp.py:150-157; GemmProblem::upd_p has the arithmetic).  A tensor takes the fused epilogue when its h comes out
+// of a grouped-GEMM product (one or two dense factors, <= 2-D), the parameters are fp32, 16-byte aligned, and its logical row length is
+// a multiple of 4; every other tensor (1-D, N-D, odd row lengths) is updated by the streaming pass as before, in the same call.  Small
+// plans whose products run on the K-split kernel, and bf16 parameters, take the unfused route whole.  The RMS clip is applied
+// speculatively (scale 1) and corrected per tensor by clip_fix_kernel when it engages: the corrected parameter differs from the
+// two-pass result by at most one fp32 rounding (p' + lr c1 - lr c2 instead of p keep - lr c2).
+static int build_fused(psgdk_plan* P, int source, void* const* params) {
+    unsigned char* W = P->work;
+    P->f_app_a.probs = P->g_app_a[source].probs;
+    P->f_app_b.probs = P->g_app_b.probs;
+    std::vector<char> fused(P->n_tensors, 0);
+    std::vector<FixDesc> fix;
+    auto fuse = [&](GemmProblem& g, int t) {
+        const TensorDesc& D = P->td[t];
+        if (((uintptr_t)params[t] & 15) || (D.lcols & 3) || D.kind == TK_GEN) return;
+        g.upd_p = (float*)params[t]; g.upd_ld = D.lcols; g.upd_nr = D.lrows; g.upd_nc = D.lcols;
+        if (D.transposed) {      // held transposed: produce h t-major = in the parameter's own orientation ([C][Rp])
+            g.Ct = g.C; g.ldct = D.Rp; g.C = nullptr; g.flags |= GF_TMAJOR;
+        }
+        fused[t] = 1;
+        fix.push_back(FixDesc{t, D.lrows, D.lcols, D.transposed ? D.Rp : D.Cp, (long long)D.numel_clip, (unsigned long long)D.h_off, (float*)params[t]});
+    };
+    for (size_t i = 0; i < P->f_app_a.probs.size(); ++i)
+        if (P->td[P->app_a_tensor[i]].kind == TK_M1) fuse(P->f_app_a.probs[i], P->app_a_tensor[i]);
+    for (size_t i = 0; i < P->f_app_b.probs.size(); ++i) fuse(P->f_app_b.probs[i], P->app_b_tensor[i]);
+    decide_tiling(P, &P->f_app_a);
+    decide_tiling(P, &P->f_app_b);
+    P->fused_any = !fix.empty() && !P->f_app_a.ksplit && !P->f_app_b.ksplit;
+    if (!P->fused_any) return PSGDK_OK;
+    int rc;
+    if ((rc = finish_stage(P->f_app_a)) || (rc = finish_stage(P->f_app_b))) return rc;
+    std::vector<EwTile> rest;
+    for (int t = 0; t < P->n_tensors; ++t) {
+        if (fused[t]) continue;
+        const TensorDesc& D = P->td[t];
+        const int th = D.wide ? 16 : 64, tw = D.wide ? 256 : 64;
+        for (int tr = 0; tr < (D.R + th - 1) / th; ++tr)
+            for (int tc = 0; tc < (D.C + tw - 1) / tw; ++tc) rest.push_back(EwTile{t, tr, tc});
+    }
+    P->n_tiles_rest = (unsigned)rest.size(); P->n_fix = (unsigned)fix.size();
+    if ((rc = upload(&P->d_tiles_rest, rest)) || (rc = upload(&P->d_fix, fix))) return rc;
+    (void)W;
+    return PSGDK_OK;
+}
+
+int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, int param_dtype, float lr, float decoupled_wd,
+                             float max_avg_amp, float max_elem_amp, void* stream) {
+    if (!plan || !params || (source != PSGDK_SRC_EMA && source != PSGDK_SRC_GRAD) || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32))
+        return PSGDK_ERR_INVALID;
+    if (!plan->state) return PSGDK_ERR_STATE;
+    if (source == PSGDK_SRC_EMA && !plan->use_momentum) return PSGDK_ERR_INVALID;
+    if (!(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
+    for (int t = 0; t < plan->n_tensors; ++t) if (!params[t]) return PSGDK_ERR_INVALID;
+    psgdk_plan* P = plan;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    bool fusable = param_dtype == PSGDK_F32 && P->shards.empty() && !P->no_fuse;
+    if (fusable) {
+        // the stages carry the callers' parameter pointers: rebuilt when a pointer, the source or the plan's tables change (a synchronous
+        // table upload; parameters keep their storage from step to step, so this happens once)
+        std::vector<const void*> key(params, params + P->n_tensors);
+        key.push_back((const void*)(uintptr_t)(source + 1));
+        if (key != P->fused_key) {
+            if ((rc = build_fused(P, source, params))) return rc;
+            P->fused_key = key;
+        }
+        fusable = P->fused_any;
+    }
+    if (!fusable) {
+        if ((rc = psgdk_precond_grad(plan, source, stream))) return rc;
+        return psgdk_apply_update(plan, params, param_dtype, lr, decoupled_wd, max_avg_amp, max_elem_amp, stream);
+    }
+    ProfCall prof_call(plan, stream);
+    if (!P->hsq_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
+    P->hsq_clean = false;
+    if ((rc = ensure_P(P, st))) return rc;
+    const GemmUpdArgs upd{lr, 1.0f - decoupled_wd * lr, max_elem_amp, decoupled_wd != 0.f ? 1 : 0};
+    launch_stage(P, P->f_app_a, st, &upd);
+    launch_stage(P, P->f_app_b, st, &upd);
+    P->h_fused = true;
+    for (const GenDesc& g : P->gd) {
+        const TensorDesc& D = P->td[g.tensor];
+        DISPATCH_T(P, {
+            const T* src = source == PSGDK_SRC_GRAD ? (const T*)(P->work + D.gc_off) : (const T*)(P->state + D.ema_off);
+            gen_apply_chain<T>(P, g, src, (T*)(P->work + D.h_off), (float*)(P->work + P->hsumsq_off) + g.tensor, st);
+        });
+    }
+    if (P->n_tiles_diag)
+        DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
+                                         P->d_tiles_diag, P->state, P->work, 1, source == PSGDK_SRC_GRAD ? 1 : 0,
+                                         (float*)(P->work + P->hsumsq_off), P->p_mode() ? 1 : 0));
+    void** d_params = nullptr;
+    if ((rc = P->ptrs_b.get((const void* const*)params, P->n_tensors, st, &d_params))) return rc;
+    // the tensors the fused epilogue does not cover: clip + update as psgdk_apply_update does it ...
+    if (P->n_tiles_rest)
+        DISPATCH_T(P, hipLaunchKernelGGL(emit_kernel<T>, dim3(P->n_tiles_rest), dim3(256), 0, st, P->d_td, P->d_tiles_rest,
+                                         (void* const*)d_params, param_dtype, P->work, (const float*)(P->work + P->hsumsq_off), 0, 1, lr,
+                                         decoupled_wd, max_avg_amp, max_elem_amp, (void*)nullptr));
+    // ... and the correction of the fused tensors whose RMS clip engaged (normally none: every workgroup scans the sums and leaves)
+    DISPATCH_T(P, hipLaunchKernelGGL(clip_fix_kernel<T>, dim3(std::min(P->n_fix * 8u, 1024u)), dim3(256), 0, st, (const FixDesc*)P->d_fix, (int)P->n_fix,
+                                     P->work, (const float*)(P->work + P->hsumsq_off), lr, max_avg_amp, max_elem_amp));
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }
@@ -1743,6 +1831,7 @@ int psgdk_read_precond_grad(psgdk_plan* plan, int t, void* out, int out_dtype, i
                             float max_elem_amp, void* stream) {
     if (!plan || t < 0 || t >= plan->n_tensors || !out || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
+    if (plan->h_fused) return PSGDK_ERR_STATE;      // the last h was consumed by psgdk_precond_grad_apply (fused tensors: applied, logical orientation)
     hipStream_t st = (hipStream_t)stream;
     const unsigned b = plan->tile_begin[t], e = plan->tile_begin[t + 1];
     DISPATCH_T(plan, hipLaunchKernelGGL(emit_kernel<T>, dim3(e - b), dim3(256), 0, st, plan->d_td, plan->d_tiles_all + b,
@@ -1756,6 +1845,7 @@ int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype
                               void* stream) {
     if (!plan || !outs || (out_dtype != PSGDK_BF16 && out_dtype != PSGDK_F32)) return PSGDK_ERR_INVALID;
     if (!plan->state) return PSGDK_ERR_STATE;
+    if (plan->h_fused) return PSGDK_ERR_STATE;      // the last h was consumed by psgdk_precond_grad_apply (fused tensors: applied, logical orientation)
     for (int t = 0; t < plan->n_tensors; ++t) if (!outs[t]) return PSGDK_ERR_INVALID;
     ProfCall prof_call(plan, stream);
     hipStream_t st = (hipStream_t)stream;
@@ -1859,76 +1949,16 @@ int psgdk_test_dump_noise(psgdk_plan* plan, uint64_t seed, uint64_t offset, void
     return PSGDK_OK;
 }
 
-int psgdk_test_clock(float* shader_mhz, void* stream) {
-    if (!shader_mhz) return PSGDK_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const unsigned grid = (unsigned)cus * 2;
-    unsigned long long* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, (size_t)grid * 2 * sizeof(unsigned long long)));
-    std::vector<unsigned long long> h((size_t)grid * 2);
-    int rc = PSGDK_OK;
-    for (int rep = 0; rep < 2; ++rep)          // (the first launch brings the clocks up)
-        hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(256), 0, st, d, 40000);
-    if (hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) rc = PSGDK_ERR_HIP;
-    (void)hipFree(d);
-    if (rc) return rc;
-    std::vector<double> mhz;
-    for (unsigned b = 0; b < grid; ++b) if (h[2 * b + 1] > 0) mhz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
-    if (mhz.empty()) return PSGDK_ERR_HIP;
-    std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
-    *shader_mhz = (float)mhz[mhz.size() / 2];
+int psgdk_test_fuse_mode(psgdk_plan* plan, int on) {
+    if (!plan) return PSGDK_ERR_INVALID;
+    plan->no_fuse = !on;
     return PSGDK_OK;
 }
 
-int psgdk_test_peaks(float* out4, void* scratch, size_t scratch_bytes, void* stream) {
-    if (!out4 || !scratch || scratch_bytes < (size_t)64 << 20) return PSGDK_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int rc = PSGDK_OK;
-    auto timed = [&](auto&& launch, int reps) -> float {          // best of `reps` launches, ms
-        float best = 1e30f;
-        launch();                                                  // warm-up (clocks, code)
-        for (int r = 0; r < reps; ++r) {
-            (void)hipEventRecord(e0, st);
-            launch();
-            (void)hipEventRecord(e1, st);
-            if (hipEventSynchronize(e1) != hipSuccess) { rc = PSGDK_ERR_HIP; return best; }
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            best = std::min(best, ms);
-        }
-        return best;
-    };
-    const int iters = 4000;
-    const unsigned grid = (unsigned)cus * 2;                       // two waves per SIMD
-    const double flops = (double)grid * 4 * iters * 16 * 16384.0;  // per wave and round: 16 MFMAs of 16 x 16 x 32 (2^18 FLOP); the 32 x 32 x 16 round is 16 MFMAs of twice that
-    float* sink = (float*)scratch;
-    const float ms16 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
-    const float ms32 = timed([&] { hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(grid), dim3(256), 0, st, sink, iters); }, 3);
-    out4[0] = (float)(flops / (ms16 * 1e-3) / 1e12);
-    out4[1] = (float)(2.0 * flops / (ms32 * 1e-3) / 1e12);
-    const size_t half = (scratch_bytes / 2) & ~(size_t)255, n = half / 16;
-    const u32x4_t* src = (const u32x4_t*)scratch;
-    u32x4_t* dst = (u32x4_t*)((unsigned char*)scratch + half);
-    // two launch shapes each (a resident grid with four chunks in flight per thread; one chunk per thread): the better one counts
-    const unsigned cgrid = (unsigned)cus * 8, fgrid = (unsigned)((n + 255) / 256);
-    const float msc = std::min(timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 0); }, 3),
-                               timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(fgrid), dim3(256), 0, st, src, dst, n, 0); }, 3));
-    const float msr = std::min(timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(cgrid), dim3(256), 0, st, src, dst, n, 1); }, 3),
-                               timed([&] { hipLaunchKernelGGL(hbm_copy_kernel, dim3(fgrid), dim3(256), 0, st, src, dst, n, 1); }, 3));
-    out4[2] = (float)(2.0 * (double)half / (msc * 1e-3) / 1e9);    // read + write
-    out4[3] = (float)((double)half / (msr * 1e-3) / 1e9);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (hipGetLastError() != hipSuccess) rc = PSGDK_ERR_HIP;
-    return rc;
+int psgdk_test_ew_mode(psgdk_plan* plan, int mode) {
+    if (!plan || mode < 0 || mode > 3) return PSGDK_ERR_INVALID;
+    plan->ew_dbg = mode;
+    return PSGDK_OK;
 }
 
 int psgdk_test_nlb(psgdk_plan* plan, int chain, int route, uint64_t seed, uint64_t offset, float* out_vsq, void* out_v,
@@ -1985,11 +2015,6 @@ int psgdk_test_gemm_nt(const void* A, const void* B, void* C, void* Ct, int dtyp
     if (!C && Ct) P.flags |= GF_TMAJOR;      // as psgdk_plan_bind does for transposed-only outputs
     s.big = (symmetric & 1024) != 0;          // test hook: bit 10 selects the 256x256 tiling, bit 25 the 64 x 64 K-split one
     s.ksplit = (symmetric & (1 << 25)) != 0;
-    s.w4 = (symmetric & (1 << 26)) != 0;      // bit 26 (with bit 10): the four-wave 256 x 256 kernel; bits 27-28 its scheduling variant
-    s.w4_var = (symmetric >> 27) & 7;
-    s.w4p = (symmetric & (1 << 23)) != 0;      // bit 23 (with bit 10): the ping-pong four-wave kernel
-    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || !gemm_w4_takes(P))) return PSGDK_ERR_UNSUPPORTED;
-    if (s.w4p && (!s.big || dtype != PSGDK_BF16 || !gemm_w4p_takes(P))) return PSGDK_ERR_UNSUPPORTED;
     s.probs.push_back(P);
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
@@ -2018,35 +2043,27 @@ int psgdk_test_stage_bench(psgdk_plan* plan, int which, int variant, int iters, 
     if (variant == 4 && !s.big) { alt.probs = s.probs; alt.big = true; int rc = finish_stage(alt); if (rc) return rc; s = alt; }
     if (variant == 14) { alt.probs = s.probs; int rc = finish_stage(alt); if (rc) return rc; s = alt; }     // the 128 x 128 tiling, whatever was bound
     if (variant == 56) {      // as bound, output stores register-direct (16 rows x 64 B) instead of staged through the LDS
-        alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4; alt.w4p = s.w4p; alt.ksplit = s.ksplit; alt.ext = s.ext;
+        alt.probs = s.probs; alt.big = s.big; alt.ksplit = s.ksplit; alt.ext = s.ext;
         for (auto& q : alt.probs) q.flags |= GF_DBG_HALFLINES;
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
-    if (variant >= 20 && variant <= 27 && s.big) {      // the eight-wave (even) / four-wave (odd) 256 x 256 kernel: as is, no epilogue, no stores, register-direct stores
-        alt.probs = s.probs; alt.big = true; alt.w4 = (variant & 1) != 0;
+    if ((variant == 22 || variant == 24 || variant == 26) && s.big) {      // the 256 x 256 kernel: no epilogue, no stores, register-direct stores
+        alt.probs = s.probs; alt.big = true;
         for (auto& q : alt.probs) {
-            if ((variant >> 1) == 11) q.flags |= GF_DBG_NOEPI;
-            if ((variant >> 1) == 12) q.flags |= GF_DBG_NOSTORE;
-            if ((variant >> 1) == 13) q.flags |= GF_DBG_HALFLINES;
-            if (alt.w4 && !gemm_w4_takes(q)) return PSGDK_ERR_UNSUPPORTED;
+            if (variant == 22) q.flags |= GF_DBG_NOEPI;
+            if (variant == 24) q.flags |= GF_DBG_NOSTORE;
+            if (variant == 26) q.flags |= GF_DBG_HALFLINES;
         }
-        if (alt.w4 && plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
     if (variant >= 5 && variant <= 8) {      // same tiling, parts of the epilogue's work stripped / the output discarded
-        alt.probs = s.probs; alt.big = s.big; alt.w4 = s.w4;
+        alt.probs = s.probs; alt.big = s.big;
         for (auto& q : alt.probs) {
             if (variant == 5 || variant == 6) { q.row_sumsq = nullptr; q.sumsq = nullptr; }
             if (variant == 6) { q.row_scale = nullptr; q.flags &= ~(GF_SQ_ROWSCALE | GF_RSQRT_ROWSCALE); }
             if (variant == 7) q.flags |= GF_DBG_NOSTORE;
             if (variant == 8) q.flags |= GF_DBG_NOEPI;
         }
-        int rc = finish_stage(alt); if (rc) return rc; s = alt;
-    }
-    if (variant >= 30 && variant <= 32 && s.big) {      // the ping-pong four-wave kernel: as is, no epilogue, no epilogue and no DMA
-        alt.probs = s.probs; alt.big = true; alt.w4p = true; alt.w4_var = variant == 31 ? 7 : (variant == 32 ? 4 : 0);
-        if (plan->dtype != PSGDK_BF16) return PSGDK_ERR_UNSUPPORTED;
-        for (auto& q : alt.probs) if (!gemm_w4p_takes(q)) return PSGDK_ERR_UNSUPPORTED;
         int rc = finish_stage(alt); if (rc) return rc; s = alt;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -2114,13 +2131,7 @@ int psgdk_test_gemm_bench(const void* A, const void* B, void* C, void* Ct, int d
     s.big = (symmetric & 1024) != 0;
     s.one_per_tile = (symmetric & 16384) != 0;
     s.ksplit = (symmetric & (1 << 25)) != 0;
-    s.w4 = (symmetric & (1 << 26)) != 0;
-    s.w4_var = (symmetric >> 27) & 7;
-    s.w4p = (symmetric & (1 << 23)) != 0;
-    if (s.w4 && (!s.big || dtype != PSGDK_BF16 || K < 128)) return PSGDK_ERR_UNSUPPORTED;
     for (auto& q : s.probs) q.flags &= ~(1024 | 2048 | 16384 | (63 << 24) | (1 << 23));
-    if (s.w4 && !gemm_w4_takes(s.probs[0])) return PSGDK_ERR_UNSUPPORTED;
-    if (s.w4p && (!s.big || dtype != PSGDK_BF16 || !gemm_w4p_takes(s.probs[0]))) return PSGDK_ERR_UNSUPPORTED;
     int rc = finish_stage(s);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;

@@ -598,13 +598,13 @@ class KWNS4(torch.optim.Optimizer):
         return torch.distributed.all_gather_into_tensor(x, mine if in_place else mine.clone(), async_op=True)
 
     @staticmethod
-    def _device_backend_is_rccl(t) -> bool:
-        """Is the transport that will carry device tensor `t` RCCL ("nccl")?  Asked of the default group's backend FOR THE TENSOR'S DEVICE:
+    def _device_backend_is_rccl(t, group=None) -> bool:
+        """Is the transport that will carry device tensor `t` RCCL ("nccl")?  Asked of the group's (default: WORLD's) backend FOR THE TENSOR'S DEVICE:
         init_process_group() without a backend, or with "cpu:gloo,cuda:nccl", reports a composite / undefined string through
         get_backend(), and a string compare against "nccl" would then send a real RCCL job down the host-staged path (a .cpu() sync per
         chunk) without a word."""
         try:
-            pg = torch.distributed.group.WORLD
+            pg = group if group is not None else torch.distributed.group.WORLD
             be = pg._get_backend(t.device) if hasattr(pg, "_get_backend") else None
             name = be.name() if be is not None and hasattr(be, "name") else None
             if name and name.lower() in ("nccl", "rccl"):
@@ -614,7 +614,7 @@ class KWNS4(torch.optim.Optimizer):
             # (anything else -- torch's fake group, a wrapper -- : the configured string decides)
         except Exception:      # noqa: BLE001  (fake / wrapped groups: fall back to the configured string)
             pass
-        cfg = str(torch.distributed.get_backend()).lower()
+        cfg = str(torch.distributed.get_backend(group)).lower()
         if t.is_cuda and "cuda:nccl" in cfg:
             return True
         return cfg == "nccl"

@@ -72,13 +72,13 @@ class RowShardedLRA:
         """sum of a small tensor over the ranks, in rank order (same bits everywhere)"""
         if world == 1:
             return x
-        host = x.detach().cpu()
-        parts = [torch.empty_like(host) for _ in range(world)]
         if x.is_cuda and _device_backend(group, x) == "nccl":
             buf = torch.empty(world * x.numel(), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(buf, x.reshape(-1).contiguous(), group=group)
             parts = [buf[k * x.numel():(k + 1) * x.numel()].reshape(x.shape) for k in range(world)]
         else:
+            host = x.detach().cpu()        # (the host copy -- a sync -- only where the transport needs it)
+            parts = [torch.empty_like(host) for _ in range(world)]
             dist.all_gather(parts, host, group=group)
             parts = [p.to(x.device) for p in parts]
         tot = parts[0].clone()
@@ -108,7 +108,7 @@ class RowShardedLRA:
 def _device_backend(group, t: torch.Tensor) -> str:
     """"nccl" when RCCL will carry device tensor `t` (the same test KWNS4's exchanges use: asked of the backend FOR THE TENSOR'S DEVICE)."""
     from .kwns4 import KWNS4
-    return "nccl" if KWNS4._device_backend_is_rccl(t) else "other"
+    return "nccl" if KWNS4._device_backend_is_rccl(t, group) else "other"
 
 
 def all_gather_rows(local: torch.Tensor, N: int, world: int, rank: int, group=None, align: int = 256) -> torch.Tensor:
