@@ -299,8 +299,8 @@ def secondary_workloads():
     the workload's own roofline fraction, so that the driver's record carries all of them.  Not part of `value`."""
     import subprocess
     res = {}
-    for name, extra, steps in (("lenet5", [], 200), ("vit-b-lra", [], 10), ("gpt2-medium", [], 10)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline",
+    for name, extra, steps in (("lenet5", [], 200), ("vit-b-lra", [], 10), ("vit-b-lra-bf16", ["--bf16"], 10), ("gpt2-medium", [], 10)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name.replace("-bf16", ""), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline",
                "--no-secondary", "--no-apply-only", "--no-peaks"] + extra
         t0 = time.perf_counter()
         try:
@@ -312,7 +312,8 @@ def secondary_workloads():
                          "value": d["value"], "unit": d["unit"], "steps": d["steps"], "dtype": d["dtype"],
                          "roofline_bound": rf.get("bound"), "roofline_frac": rf.get("frac"), "roofline_achieved": rf.get("achieved"),
                          "roofline_unit": rf.get("unit"), "whole_step_frac_of_peak": rf.get("whole_step_frac_of_peak"),
-                         "launches_per_step": d["config"].get("launches_per_step"), "wall_s": time.perf_counter() - t0}
+                         "launches_per_step": d["config"].get("launches_per_step"),
+                         "host_enqueue_ms_per_step": d["config"].get("host_enqueue_ms_per_step"), "wall_s": time.perf_counter() - t0}
         except Exception as e:      # noqa: BLE001  (a secondary figure must never take the headline line down)
             res[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
@@ -335,6 +336,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (BASELINE configs 2, 4, 5) that the default "
                                                                 "single-GPU run times after the headline and reports under config.secondary")
     ap.add_argument("--no-peaks", action="store_true", help="skip the in-process ceiling measurement (roofline.peak_measured)")
+    ap.add_argument("--no-fuse", action="store_true", help="A/B: the parameter update as its own streaming pass (psgdk_apply_update) instead of "
+                    "fused into the epilogue of the apply's last product (psgdk_precond_grad_apply)")
+    ap.add_argument("--fuse-stagger", type=int, default=-1, help="experiment: GemmUpdArgs::stagger of the fused launches in 100 MHz ticks "
+                    "(-1: the library's default)")
     ap.add_argument("--fp32", action="store_true", help="fp32 preconditioner instead of bf16 (not the headline config)")
     ap.add_argument("--bf16", action="store_true", help="vit-b-lra only: bf16 factors and vectors instead of fp32 (SURVEY 8d quotes both)")
     ap.add_argument("--config", default="gpt2-small", choices=["gpt2-small", "gpt2-medium", "lenet5", "vit-b-lra", "gpt2-small-eq"],
@@ -414,8 +419,10 @@ def main():
 
     def make(mode_name):
         ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
-        return ps, psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, whiten_grad=args.whiten_grad,
-                                        **MODES[mode_name])                                # reference defaults otherwise
+        o = psgd_torch_amd.KWNS4(ps, preconditioner_dtype=pd, whiten_grad=args.whiten_grad,
+                                 **MODES[mode_name])                                       # reference defaults otherwise
+        o._fuse_update = not args.no_fuse
+        return ps, o
 
     def step_of(ps, o):
         def f(i):
@@ -484,6 +491,8 @@ def main():
     for e in engines:
         e.profile_read(reset=True)
         e.profile_enable(False)
+        if args.fuse_stagger >= 0:
+            e.fuse_update(not args.no_fuse, args.fuse_stagger)
     gc.collect()
     gc_before = [g["collections"] for g in gc.get_stats()]
     gc.callbacks.append(gc_watch)
@@ -503,7 +512,11 @@ def main():
     # one event per step boundary on the stream the engine launches on (torch's current stream): no fences, nothing waits on them
     # until the timed region is over; the per-step device times give the median / min next to the wall-clock mean
     sampled = []
+    import ctypes as _C
+    from psgd_torch_amd import _lib as _L
+    _nl = _C.c_int64()
     fence()
+    _L.check(_L.lib().psgdk_test_launch_count(_C.byref(_nl), 1), "launch_count")      # (reset: the timed region's launches are counted)
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.steps):
@@ -516,6 +529,8 @@ def main():
         one_step(n_warm + i)
         step_ev[i + 1].record()
     host_dt = time.perf_counter() - t0          # host enqueue time (no sync inside): shows whether the host keeps ahead
+    _L.check(_L.lib().psgdk_test_launch_count(_C.byref(_nl), 0), "launch_count")
+    kernel_launches_per_step = _nl.value / args.steps
     fence()
     dt = time.perf_counter() - t0
     per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
@@ -622,6 +637,9 @@ def main():
                    "parallelism_probe_ms": ({k: (v * 1e3 if math.isfinite(v) else None) for k, v in timing.items()}
                                             if (dist and args.parallelism == "auto") else None),
                    "step_gflop_model": step_flops / 1e9, "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+                   "launches_per_step": kernel_launches_per_step,      # every kernel the library launched in the timed region / steps
+                   "param_update": ("fused into the epilogue of the apply's last product (psgdk_precond_grad_apply)" if not (args.no_fuse or dist)
+                                    else "separate streaming pass"),
                    "step_device_ms": [round(x, 4) for x in per_step],      # every timed step, in order (event to event on the launch stream)
                    "gc_in_timed_region": gc_in_timed, "apply_only_ms_per_step": apply_only_ms,
                    "norm_bound_route": "cooperative launch (device-scope exchange)" if nlb_coop else "grouped-GEMM products",
@@ -643,9 +661,10 @@ def main():
                 traffic_lib = tj.get("library_sha256")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_nt_pipe_kernel <bf16> (all grouped-GEMM launches of the step: the "
+        out["roofline"] = {"bound": "mfma" if args.config != "lenet5" else "latency",      # (LeNet5 is launch-latency bound: us / step and launches / step are its figures)
+                           "kernel": "gemm_nt_kernel + gemm_nt_pipe_kernel <bf16> (all grouped-GEMM launches of the step: the "
                                                       "128 x 128 tiling and the persistent 256 x 256 one)"
-                           if not args.fp32 else "gemm_nt_kernel<float>",
+                           if not args.fp32 else ("gemm_nt_kernel<float>" if args.config != "lenet5" else "gemm_nt_ks_kernel<float>"),
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic,
                            # the counters were collected on the library whose hash the profile carries; a different library now = stale

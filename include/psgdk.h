@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 401    /* round 5 (401): row shards of the LRA preconditioner (psgdk_lra_set_row_shard, psgdk_lra_update_phase / _apply_phase / _phase_segments);
+#define PSGDK_VERSION 402    /* round 6 (402): psgdk_precond_grad_apply (the parameter update fused into the apply's last product);
+                                round 5 (401): row shards of the LRA preconditioner (psgdk_lra_set_row_shard, psgdk_lra_update_phase / _apply_phase / _phase_segments);
                                 round 4 (400): row shards (psgdk_plan_set_row_shard, psgdk_update_precond_begin / _finish, psgdk_balance_phase),
                                 psgdk_profile_read_calls; (300: test hooks moved to psgdk_test.h; 200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
 #define PSGDK_MAX_DIMS 26     /* most dims of one tensor: the reference's own limit (einsum letters, psgd.py:197-198) */
@@ -193,6 +194,18 @@ int psgdk_precond_grad(psgdk_plan* plan, int source, void* stream);
 int psgdk_apply_update(psgdk_plan* plan, void* const* params, int param_dtype, float lr, float decoupled_wd,
                        float max_avg_amp, float max_elem_amp, void* stream);
 
+/* ---- psgdk_precond_grad followed by psgdk_apply_update, as ONE call (..._ddp.py:150-157) ----
+ * Same arguments, same result as the two calls.  Where a tensor allows it (its h leaves a grouped-GEMM product; fp32 parameters,
+ * 16-byte aligned, logical row length a multiple of 4) the parameter update runs INSIDE the epilogue of that product -- the h tile is
+ * in registers there, so the separate pass over h and p (10 B / parameter) disappears; every other tensor is updated by the streaming
+ * pass within the same call.  The RMS clip (..._ddp.py:153-155) needs the whole tensor's sum of h^2, which the product itself
+ * accumulates: the fused update is applied with clip scale 1 and a tensor whose RMS turns out above max_avg_amp is corrected afterwards
+ * (p + lr clamp(h) - lr clamp(h scale): at most one fp32 rounding away from the two-call result; identical bits when no clip engages).
+ * Afterwards h is CONSUMED: psgdk_apply_update / psgdk_read_precond_grad / psgdk_export_precond_grad return PSGDK_ERR_STATE until the next
+ * psgdk_precond_grad.  Plans with row shards, bf16 parameters and small plans on the K-split kernel take the two-call route inside. */
+int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, int param_dtype, float lr, float decoupled_wd,
+                             float max_avg_amp, float max_elem_amp, void* stream);
+
 /* Sharded path (build-side design): the clipped preconditioned gradients (wrapped_as_torch_optimizer_for_ddp.py:153-156)
  * of ALL tensors of the plan, exported in one launch to caller buffers outs[t] (logical contiguous order, element type
  * out_dtype) -- normally this rank's slices of the flat all-gather buffer. */
@@ -284,6 +297,8 @@ int psgdk_lra_phase_segments(const psgdk_lra* lra, int kind, int phase, int* n_s
                                         read by the clip of psgdk_apply_update / psgdk_export_precond_grad): a row shard's entry is summed
                                         over the members by the caller in between */
 #define PSGDK_INFO_BALNORM_OFFSET 5  /* byte offset in the WORK arena of the balancing slots of psgdk_balance_phase */
+#define PSGDK_INFO_UPDATE_FUSED 6    /* how many tensors' parameter updates ran inside a GEMM epilogue in the last psgdk_precond_grad_apply
+                                        (0: it took the two-call route, or the last h came from psgdk_precond_grad) */
 int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
 
 /* ---- row shards: the sharded (multi-GPU) path's split of a DOMINANT tensor (new; the reference only replicates -- SURVEY 8e.  GPT-2's

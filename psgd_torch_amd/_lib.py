@@ -7,12 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE, PSGDK_ERR_NLB_TIMEOUT = 0, 1, 2, 3, 4, 5
-INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM, INFO_HSUMSQ_OFFSET, INFO_BALNORM_OFFSET = 0, 1, 2, 3, 4, 5
+INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM, INFO_HSUMSQ_OFFSET, INFO_BALNORM_OFFSET, INFO_UPDATE_FUSED = 0, 1, 2, 3, 4, 5, 6
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 401      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 402      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "psgdk_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "psgdk_apply_update": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_void_p]),
+    "psgdk_precond_grad_apply": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.c_void_p]),
     "psgdk_export_precond_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "psgdk_read_precond_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                           C.c_void_p]),
@@ -115,6 +117,8 @@ SIGNATURES = {
 # include/psgdk_test.h: kernel-level test / benchmark hooks (same library, not part of the drop-in ABI)
 TEST_SIGNATURES = {
     "psgdk_test_ew_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "psgdk_test_fuse_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "psgdk_test_launch_count": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "psgdk_test_dump_noise": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "psgdk_test_nlb_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -89,6 +89,8 @@ struct psgdk_plan {
     Stage f_app_a, f_app_b;
     std::vector<int> app_a_tensor, app_b_tensor;     // per problem of g_app_a[.] / g_app_b: its tensor
     std::vector<const void*> fused_key;              // [params..., (void*)src] the fused stages were built for; empty = not built
+    int fused_rebuilds = 0;
+    int fuse_stagger = 0;            // GemmUpdArgs::stagger of the fused launches, 100 MHz ticks, in bits 0..23; bits 24..: GemmUpdArgs::dbg (psgdk_test_fuse_mode)
     bool fused_any = false;                          // at least one tensor takes the fused epilogue (otherwise the call runs unfused)
     bool h_fused = false;                            // the work arena's h was produced by the fused stages: fused tensors' h is in LOGICAL
                                                      // orientation and already applied -- read / export / apply_update refuse it
@@ -190,11 +192,11 @@ static unsigned persistent_grid(unsigned n_tiles) {
 //  packet, so a profiled launch costs no extra packets on the stream, unlike a hipEventRecord pair, which fences it: 0.13 ms per step)
 #define PSGDK_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                               \
     do {                                                                                                     \
-        if (e0) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, e0, e1, 0, __VA_ARGS__);                   \
+        if (e0) { ++g_psgdk_launches; hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, e0, e1, 0, __VA_ARGS__); }   \
         else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__);                                    \
     } while (0)
 template <typename T>
-void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const GemmUpdArgs upd = GemmUpdArgs{0.f, 1.f, 0.f, 0}) {
+void launch_stage_t(const Stage& s, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const GemmUpdArgs upd = GemmUpdArgs{0.f, 1.f, 0.f, 0, 0, 0}) {
     if (!s.n_tiles) return;
     if (s.big) PSGDK_LAUNCH(gemm_nt_pipe_kernel<T>, dim3(s.one_per_tile ? s.n_tiles : persistent_grid(s.n_tiles)), dim3(512),
                                  s.d_probs, s.d_tiles, (int)s.n_tiles, upd);
@@ -214,7 +216,7 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st, const GemmUpdAr
         e0 = p->prof_ev[p->prof_used].first; e1 = p->prof_ev[p->prof_used].second;
         ++p->prof_used;
     }
-    const GemmUpdArgs u = upd ? *upd : GemmUpdArgs{0.f, 1.f, 0.f, 0};
+    const GemmUpdArgs u = upd ? *upd : GemmUpdArgs{0.f, 1.f, 0.f, 0, 0, 0};
     if (p->dtype == PSGDK_BF16) launch_stage_t<bf16_t>(s, st, e0, e1, u); else launch_stage_t<float>(s, st, e0, e1, u);
 }
 
@@ -1139,6 +1141,7 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
         void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
+        ++g_psgdk_launches;
         HIPCHK(hipLaunchKernel(k, dim3(P->n_nlb_jobs), dim3(512), args, P->nlb_lds, st));
         return PSGDK_OK;
     }
@@ -1668,12 +1671,16 @@ static int build_fused(psgdk_plan* P, int source, void* const* params) {
         fused[t] = 1;
         fix.push_back(FixDesc{t, D.lrows, D.lcols, D.transposed ? D.Rp : D.Cp, (long long)D.numel_clip, (unsigned long long)D.h_off, (float*)params[t]});
     };
-    for (size_t i = 0; i < P->f_app_a.probs.size(); ++i)
-        if (P->td[P->app_a_tensor[i]].kind == TK_M1) fuse(P->f_app_a.probs[i], P->app_a_tensor[i]);
-    for (size_t i = 0; i < P->f_app_b.probs.size(); ++i) fuse(P->f_app_b.probs[i], P->app_b_tensor[i]);
+    // (the tiling of a stage does not depend on the fusion; a stage on the K-split kernel of small launches keeps the two-pass update
+    //  for its tensors: that kernel's epilogue does not carry the fused form)
     decide_tiling(P, &P->f_app_a);
     decide_tiling(P, &P->f_app_b);
-    P->fused_any = !fix.empty() && !P->f_app_a.ksplit && !P->f_app_b.ksplit;
+    if (!P->f_app_a.ksplit)
+        for (size_t i = 0; i < P->f_app_a.probs.size(); ++i)
+            if (P->td[P->app_a_tensor[i]].kind == TK_M1) fuse(P->f_app_a.probs[i], P->app_a_tensor[i]);
+    if (!P->f_app_b.ksplit)
+        for (size_t i = 0; i < P->f_app_b.probs.size(); ++i) fuse(P->f_app_b.probs[i], P->app_b_tensor[i]);
+    P->fused_any = !fix.empty();
     if (!P->fused_any) return PSGDK_OK;
     int rc;
     if ((rc = finish_stage(P->f_app_a)) || (rc = finish_stage(P->f_app_b))) return rc;
@@ -1708,11 +1715,14 @@ int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, 
         // table upload; parameters keep their storage from step to step, so this happens once)
         std::vector<const void*> key(params, params + P->n_tensors);
         key.push_back((const void*)(uintptr_t)(source + 1));
-        if (key != P->fused_key) {
+        if (key != P->fused_key && P->fused_rebuilds < 16) {
+            // (a caller that hands over fresh pointers every step -- packed shadows of strided parameters -- would pay a synchronous table
+            //  upload per step: after 16 rebuilds the plan stays on the two-call route)
+            ++P->fused_rebuilds;
             if ((rc = build_fused(P, source, params))) return rc;
             P->fused_key = key;
         }
-        fusable = P->fused_any;
+        fusable = P->fused_any && key == P->fused_key;
     }
     if (!fusable) {
         if ((rc = psgdk_precond_grad(plan, source, stream))) return rc;
@@ -1722,7 +1732,7 @@ int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, 
     if (!P->hsq_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
     P->hsq_clean = false;
     if ((rc = ensure_P(P, st))) return rc;
-    const GemmUpdArgs upd{lr, 1.0f - decoupled_wd * lr, max_elem_amp, decoupled_wd != 0.f ? 1 : 0};
+    const GemmUpdArgs upd{lr, 1.0f - decoupled_wd * lr, max_elem_amp, decoupled_wd != 0.f ? 1 : 0, P->fuse_stagger & 0xffffff, P->fuse_stagger >> 24};
     launch_stage(P, P->f_app_a, st, &upd);
     launch_stage(P, P->f_app_b, st, &upd);
     P->h_fused = true;
@@ -1868,6 +1878,7 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
         case PSGDK_INFO_MAX_DENSE_DIM: *value = plan->max_dp; return PSGDK_OK;
         case PSGDK_INFO_HSUMSQ_OFFSET: *value = (int64_t)plan->hsumsq_off; return PSGDK_OK;
         case PSGDK_INFO_BALNORM_OFFSET: *value = (int64_t)plan->balnorm_off; return PSGDK_OK;
+        case PSGDK_INFO_UPDATE_FUSED: *value = plan->h_fused ? (int64_t)plan->n_fix : 0; return PSGDK_OK;
     }
     return PSGDK_ERR_INVALID;
 }
@@ -1949,9 +1960,17 @@ int psgdk_test_dump_noise(psgdk_plan* plan, uint64_t seed, uint64_t offset, void
     return PSGDK_OK;
 }
 
-int psgdk_test_fuse_mode(psgdk_plan* plan, int on) {
-    if (!plan) return PSGDK_ERR_INVALID;
+int psgdk_test_launch_count(int64_t* count, int reset) {
+    if (!count) return PSGDK_ERR_INVALID;
+    *count = (int64_t)g_psgdk_launches;
+    if (reset) g_psgdk_launches = 0;
+    return PSGDK_OK;
+}
+
+int psgdk_test_fuse_mode(psgdk_plan* plan, int on, int stagger_ticks) {
+    if (!plan || stagger_ticks < -1) return PSGDK_ERR_INVALID;
     plan->no_fuse = !on;
+    if (stagger_ticks >= 0) plan->fuse_stagger = stagger_ticks;
     return PSGDK_OK;
 }
 

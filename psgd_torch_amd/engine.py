@@ -176,12 +176,12 @@ class KronEngine:
             with torch.cuda.device(self.device):
                 # `members` records (this member's is written by update_begin; the caller all-gathers the buffer IN PLACE)
                 self.xchg = torch.zeros(members * rb.value, dtype=torch.uint8, device=self.device)
-            hoff, boff = C.c_int64(), C.c_int64()
-            L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_HSUMSQ_OFFSET, C.byref(hoff)), "plan_info")
-            L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_BALNORM_OFFSET, C.byref(boff)), "plan_info")
-            # device views the caller reduces over the members: the shards' sums of h^2 (one float each), the balancing slots
-            self.hsumsq = self.work_arena[hoff.value:hoff.value + 4 * self.n].view(torch.float32)
-            self.balnorm = self.work_arena[boff.value:boff.value + 8 * self.n].view(torch.float32)
+        hoff, boff = C.c_int64(), C.c_int64()
+        L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_HSUMSQ_OFFSET, C.byref(hoff)), "plan_info")
+        L.check(self.lib.psgdk_plan_info(self._plan, L.INFO_BALNORM_OFFSET, C.byref(boff)), "plan_info")
+        # device views: the tensors' sums of h^2 (one float each; row shards: the caller reduces them over the members), the balancing slots
+        self.hsumsq = self.work_arena[hoff.value:hoff.value + 4 * self.n].view(torch.float32)
+        self.balnorm = self.work_arena[boff.value:boff.value + 8 * self.n].view(torch.float32)
         self._keep = []        # host pointer arrays kept alive until the next call
         if init_scale is not None:
             self.init_state(init_scale)
@@ -395,6 +395,21 @@ class KronEngine:
                                             float(max_avg_amp), float(max_elem_amp), self._stream()), "apply_update")
 
     @_on_device
+    def precond_grad_apply(self, source: int, params: Sequence[torch.Tensor], lr: float, decoupled_wd: float, max_avg_amp: float,
+                           max_elem_amp: float):
+        """precond_grad + apply_update as one call (..._ddp.py:150-157): the parameter update runs inside the epilogue of the apply's last
+        product wherever a tensor allows it (include/psgdk.h: psgdk_precond_grad_apply); h is consumed."""
+        _check_tensors("params", params, self.numels, self.device)
+        pa = L.ptr_array(params)
+        self._keep_p = [pa, list(params)]
+        L.check(self.lib.psgdk_precond_grad_apply(self._plan, int(source), pa, L.dtype_code(params[0].dtype), float(lr), float(decoupled_wd),
+                                                  float(max_avg_amp), float(max_elem_amp), self._stream()), "precond_grad_apply")
+
+    def fuse_update(self, on: bool, stagger_ticks: int = -1):
+        """test / A-B hook: False = precond_grad_apply takes the two-call route on this engine; stagger_ticks: see include/psgdk_test.h"""
+        L.check(self.lib.psgdk_test_fuse_mode(self._plan, int(bool(on)), int(stagger_ticks)), "test_fuse_mode")
+
+    @_on_device
     def read_precond_grad(self, t: int, out: Optional[torch.Tensor] = None, clip: bool = False, max_avg_amp: float = 2.0,
                           max_elem_amp: float = 10.0) -> torch.Tensor:
         if out is None:
@@ -439,7 +454,8 @@ class KronEngine:
         """How the plan runs (psgdk_plan_info): cooperative norm-bound launch on / how often a timeout switched it off."""
         out = {}
         for name, code in (("nlb_coop", L.INFO_NLB_COOP), ("nlb_fallbacks", L.INFO_NLB_FALLBACKS),
-                           ("dense_factors", L.INFO_DENSE_FACTORS), ("max_dense_dim", L.INFO_MAX_DENSE_DIM)):
+                           ("dense_factors", L.INFO_DENSE_FACTORS), ("max_dense_dim", L.INFO_MAX_DENSE_DIM),
+                           ("update_fused", L.INFO_UPDATE_FUSED)):
             v = C.c_int64()
             L.check(self.lib.psgdk_plan_info(self._plan, code, C.byref(v)), "plan_info")
             out[name] = int(v.value)

@@ -565,11 +565,19 @@ class KWNS4(torch.optim.Optimizer):
                            keep_grad=bool(group["whiten_grad"]) or momentum == 0.0, damp=damp)
             if updateP_first:
                 yield from update(2 * t)
-            eng.precond_grad(src_p)
+            fused = not self.shard_state and not shard_k and getattr(self, "_fuse_update", True) and hasattr(eng, "precond_grad_apply")
+            if fused:
+                # ..._ddp.py:150-157 in one call: the update of p rides in the epilogue of the product that forms h
+                eng.precond_grad_apply(src_p, own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
+                _unpack(back)
+            else:
+                eng.precond_grad(src_p)
             if shard_k:
                 # the RMS clip of a row-split tensor averages over ALL its rows (..._ddp.py:153-155): the blocks' sums of h^2 are summed
                 self._reduce_sum(eng.hsumsq, shard_k)
-            if not self.shard_state:
+            if fused:
+                pass
+            elif not self.shard_state:
                 eng.apply_update(own_p, lr, wd if (wd > 0.0 and decoupled) else 0.0, max_avg_amp, max_element_amp)
                 _unpack(back)
             else:
