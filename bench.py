@@ -539,8 +539,11 @@ def main():
     gc.callbacks.remove(gc_watch)
     gc_in_timed = {"collections_by_generation": [g["collections"] - b for g, b in zip(gc.get_stats(), gc_before)],
                    "ms_per_step": gc_ms[0] / args.steps}
-    gemm_ms, gemm_launches, call_ms = 0.0, 0, 0.0
+    gemm_ms, gemm_launches, call_ms, fused_ms, fused_launches = 0.0, 0, 0.0, 0.0, 0
     for e in engines:
+        fm, fn = e.profile_read_fused()
+        fused_ms += fm
+        fused_launches += fn
         ms, n = e.profile_read(reset=True)
         gemm_ms += ms
         gemm_launches += n
@@ -648,6 +651,9 @@ def main():
     }
     if world == 1 and gemm_launches and prof_steps:
         launches_per_step = gemm_launches / prof_steps
+        # FLOPs of the launches that carry the fused update = the apply's products S P (apply = 2 d^3 + 2 N d per dense factor, of
+        # which 2 d^3 is P = Q^T Q in a launch of its own)
+        fused_flops = float(sum(2.0 * math.prod(s) * d for s in shapes for d in s if d > 1 and d * d <= math.prod(s))) if fused_launches else 0.0
         avg_launch_s = gemm_ms / 1e3 / gemm_launches
         achieved = (gemm_flops / launches_per_step) / avg_launch_s / 1e12
         peak = 157.3 if args.fp32 else 2500.0
@@ -677,6 +683,16 @@ def main():
                            "avg_launch_us": avg_launch_s * 1e6,
                            "algorithmic_gflop_per_launch": gemm_flops / launches_per_step / 1e9,
                            "gemm_ms_per_step": gemm_ms / prof_steps, "steps_with_events": prof_steps,
+                           # round 6: the apply's last product carries the parameter update in its epilogue (10 B / parameter of HBM traffic that
+                           # the separate streaming pass of rounds 1-5 moved): that launch is slower than the bare product, the step faster.
+                           # `achieved` / `frac` above price ALL grouped-GEMM launches, the fused one included, with the products' FLOPs only.
+                           "fused_update_launch": ({"launches_per_step": fused_launches / prof_steps, "ms_per_step": fused_ms / prof_steps,
+                                                    "what": "gemm_nt_pipe_kernel carrying p <- p (1 - wd lr) - lr clamp(h) in its epilogue: the product's "
+                                                            "FLOPs plus 10 B / parameter (h out, fp32 parameter in and out)",
+                                                    "hbm_gbs_algorithmic": (nparam * 12.0 / 1e9) / (fused_ms / prof_steps * 1e-3) if fused_ms > 0 else None}
+                                                   if fused_launches else None),
+                           "frac_excluding_fused_update_launch": (((gemm_flops - fused_flops) / 1e12) / ((gemm_ms - fused_ms) / prof_steps * 1e-3) / peak
+                                                                  if fused_launches and gemm_ms > fused_ms else None),
                            "whole_step_frac_of_peak": step_flops / (dt / args.steps) / 1e12 / peak}
     if world == 1 and "roofline" in out and not args.no_peaks:
         # ceilings of THIS chip, measured in-process in < 1 s (SURVEY 8d "re-verify on the box"): register-operand MFMA loops of both

@@ -333,6 +333,9 @@ int psgdk_balance_phase(psgdk_plan* plan, const uint8_t* mask, int phase, void* 
  * Bit 1: the hot-path calls are bracketed too (below; recorded on the stream, ~4 us each). */
 int psgdk_profile_enable(psgdk_plan* plan, int enable);
 int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches, int reset);
+/* of the launches psgdk_profile_read would report: those that carried the fused parameter update (psgdk_precond_grad_apply) -- their time holds
+ * the update's memory traffic as well as the product.  Call BEFORE a resetting psgdk_profile_read. */
+int psgdk_profile_read_fused(psgdk_plan* plan, double* fused_ms, int64_t* fused_launches);
 /* bit 1 of the same switch brackets every hot-path CALL (accumulate, update, precond_grad, apply / export) by an event pair: the summed device
  * time between the first and the last kernel of each call, i.e. the engine's kernel time per step without the host in it. */
 int psgdk_profile_read_calls(psgdk_plan* plan, double* call_ms, int64_t* calls, int reset);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "psgdk_plan_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "psgdk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psgdk_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "psgdk_profile_read_fused": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "psgdk_profile_read_calls": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "psgdk_plan_set_row_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "psgdk_plan_exchange_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),

@@ -90,7 +90,7 @@ struct psgdk_plan {
     std::vector<int> app_a_tensor, app_b_tensor;     // per problem of g_app_a[.] / g_app_b: its tensor
     std::vector<const void*> fused_key;              // [params..., (void*)src] the fused stages were built for; empty = not built
     int fused_rebuilds = 0;
-    int fuse_stagger = 0;            // GemmUpdArgs::stagger of the fused launches, 100 MHz ticks, in bits 0..23; bits 24..: GemmUpdArgs::dbg (psgdk_test_fuse_mode)
+    int fuse_stagger = -1;           // GemmUpdArgs::stagger of the fused launches, 100 MHz ticks; -1 = the default (scaled with K)
     bool fused_any = false;                          // at least one tensor takes the fused epilogue (otherwise the call runs unfused)
     bool h_fused = false;                            // the work arena's h was produced by the fused stages: fused tensors' h is in LOGICAL
                                                      // orientation and already applied -- read / export / apply_update refuse it
@@ -125,6 +125,7 @@ struct psgdk_plan {
     bool prof_calls = false;      // event pairs around every hot-path call (hipEventRecord: they fence the stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev, prof_call_ev;
     size_t prof_used = 0, prof_call_used = 0;
+    std::vector<char> prof_fused;     // per profiled launch: it carried the fused parameter update (psgdk_profile_read_fused)
 
     std::vector<Stage*> all_stages() {
         std::vector<Stage*> v = {&g_P, &g_upd_a, &g_upd_b, &g_gram, &g_qupd, &g_rq, &g_rrq, &g_app_a[0], &g_app_a[1], &g_app_b, &f_app_a, &f_app_b};
@@ -214,6 +215,8 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st, const GemmUpdAr
             p->prof_ev.emplace_back(a, b);
         }
         e0 = p->prof_ev[p->prof_used].first; e1 = p->prof_ev[p->prof_used].second;
+        if (p->prof_fused.size() <= p->prof_used) p->prof_fused.resize(p->prof_used + 1);
+        p->prof_fused[p->prof_used] = upd ? 1 : 0;
         ++p->prof_used;
     }
     const GemmUpdArgs u = upd ? *upd : GemmUpdArgs{0.f, 1.f, 0.f, 0, 0, 0};
@@ -1732,7 +1735,15 @@ int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, 
     if (!P->hsq_clean || P->clean_stream != st) HIPCHK(hipMemsetAsync(P->work + P->hsumsq_off, 0, (size_t)P->n_tensors * 4, st));
     P->hsq_clean = false;
     if ((rc = ensure_P(P, st))) return rc;
-    const GemmUpdArgs upd{lr, 1.0f - decoupled_wd * lr, max_elem_amp, decoupled_wd != 0.f ? 1 : 0, P->fuse_stagger & 0xffffff, P->fuse_stagger >> 24};
+    // stagger: workgroups that walk one tile fewer start up to ~one tile time late (measured on GPT-2-small, K = 768: 4000 ticks of 10 ns:
+    // 389 -> 375 us per fused apply; scaled with K for other widths; psgdk_test_fuse_mode overrides)
+    int stagger = P->fuse_stagger;
+    if (stagger < 0) {
+        int kmax = 0;
+        for (const GemmProblem& g : P->f_app_a.probs) kmax = std::max(kmax, g.K);
+        stagger = std::min(5 * kmax, 16000);
+    }
+    const GemmUpdArgs upd{lr, 1.0f - decoupled_wd * lr, max_elem_amp, decoupled_wd != 0.f ? 1 : 0, stagger & 0xffffff, 0};
     launch_stage(P, P->f_app_a, st, &upd);
     launch_stage(P, P->f_app_b, st, &upd);
     P->h_fused = true;
@@ -1901,6 +1912,20 @@ int psgdk_profile_read(psgdk_plan* plan, double* gemm_ms, int64_t* gemm_launches
     }
     *gemm_ms = tot; *gemm_launches = (int64_t)plan->prof_used;
     if (reset) plan->prof_used = 0;
+    return PSGDK_OK;
+}
+
+int psgdk_profile_read_fused(psgdk_plan* plan, double* fused_ms, int64_t* fused_launches) {
+    if (!plan || !fused_ms || !fused_launches) return PSGDK_ERR_INVALID;
+    double tot = 0.0; int64_t n = 0;
+    for (size_t i = 0; i < plan->prof_used; ++i) {
+        if (!plan->prof_fused[i]) continue;
+        HIPCHK(hipEventSynchronize(plan->prof_ev[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, plan->prof_ev[i].first, plan->prof_ev[i].second));
+        tot += ms; ++n;
+    }
+    *fused_ms = tot; *fused_launches = n;
     return PSGDK_OK;
 }
 

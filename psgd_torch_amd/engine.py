@@ -473,6 +473,12 @@ class KronEngine:
         L.check(self.lib.psgdk_profile_read(self._plan, C.byref(ms), C.byref(n), int(reset)), "profile_read")
         return ms.value, n.value
 
+    def profile_read_fused(self):
+        """(ms, launches) of the profiled GEMM launches that carried the fused parameter update; call before a resetting profile_read"""
+        ms, n = C.c_double(), C.c_int64()
+        L.check(self.lib.psgdk_profile_read_fused(self._plan, C.byref(ms), C.byref(n)), "profile_read_fused")
+        return ms.value, n.value
+
     @_on_device
     def profile_read_calls(self, reset: bool = True):
         """(ms, calls): device time between the first and the last kernel of every hot-path call while profiling was enabled"""
