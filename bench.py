@@ -188,7 +188,10 @@ def bench_lra(args):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
     bytes_alg = (12 + 3) * N * r * esz + (18 + 3) * N * esz    # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
-    bytes_moved = (12 + 3) * N * r * esz + 24 * N * esz         # what the kernels move since round 3 (24 vector passes)
+    # what the kernels move: 24 vector passes since round 3; since round 6 the Grams of psgd.py:1006 are carried from
+    # update to update and the factors re-read for them every lra.GRAM_EVERY updates only: 2 of the 12 + 3 matrix passes run once in 16 updates
+    gram_passes = 2.0 / lra.GRAM_EVERY if (lra.GRAM_EVERY and r <= 64) else 2.0
+    bytes_moved = (10 + gram_passes + 3) * N * r * esz + 24 * N * esz
     peaks = None
     if not args.no_peaks:
         import ctypes as C
@@ -217,9 +220,15 @@ def bench_lra(args):
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "bf16" if args.bf16 else "fp32", "data": "synthetic",
            "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, {'bf16' if args.bf16 else 'fp32'}: update_precond_lra_whiten + precond_grad_lra",
-                      "rank": r},
+                      "rank": r,
+                      "gram_recurrence": (f"the Grams of psgd.py:1006 carried from update to update (r x r recurrence), the factors re-read for them every "
+                                          f"{lra.GRAM_EVERY} updates: 13 + 2/{lra.GRAM_EVERY} matrix passes per update + apply instead of 15; `achieved` prices the "
+                                          "SURVEY's 15 (algorithmic bytes of the path as the reference defines it), `moved_gbs` what the kernels moved")
+                      if (lra.GRAM_EVERY and r <= 64) else None},
            "roofline": {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_alg / dt / 1e9 / 8000.0, "traffic": traffic,
+                        "traffic_note": ("counters collected with a Gram pass in every update (rounds 2-5); since round 6 two of the fifteen matrix "
+                                         "passes run once in 16 updates: moved_gb_per_step is the current figure") if traffic else None,
                         "traffic_source": ("profiles/pmc_traffic_vit-b-lra_latest.json: separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE), "
                                            "all psgdk_lra_* launches of one update + apply") if traffic else None,
                         "algorithmic_gb_per_step": bytes_alg / 1e9,

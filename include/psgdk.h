@@ -252,6 +252,15 @@ int psgdk_lra_create(psgdk_lra** out, int64_t N, int r, int dtype);
 int psgdk_lra_destroy(psgdk_lra* lra);
 int psgdk_lra_work_bytes(const psgdk_lra* lra, size_t* work_bytes);
 int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void* work);
+/* The Grams U^T U, V^T V, V^T U of psgd.py:1006 without reading the factors (round 6; ranks <= 64, not for row shards).  An update
+ * determines the Grams of the factors it leaves behind: the rotation's follow analytically, and the rank-1 step of psgd.py:1043 / 1052
+ * changes them by outer products of r-vectors the update reduces anyway (a^T U, b^T U, a^T V, b^T V, |a|^2, |b|^2, a^T b).  With every > 0
+ * psgdk_lra_update_whiten carries them from update to update (fp32, r x r) and reads the factors for them only on the first update, every
+ * `every` updates (rounding drift; 16 is what the Python host uses) and after psgdk_lra_bind / psgdk_lra_state_changed: 2 of the 15 matrix
+ * passes of an update + apply disappear.  every = 0 (default): psgd.py:1006 as written.  A caller that writes U or V ITSELF between two
+ * updates must say so (psgdk_lra_state_changed): the engine cannot see it. */
+int psgdk_lra_set_gram_recurrence(psgdk_lra* lra, int every);
+int psgdk_lra_state_changed(psgdk_lra* lra);
 /* replaces psgd.update_precond_lra_whiten (psgd.py:1066-1072) -> update_precond_lra (psgd.py:994-1052), in place on
  * U, V, d, Luvd.  g: the N-vector to whiten; v_noise: the randn_like(g) draw of psgd.py:1070 or NULL for Philox
  * (seed, offset); update_u: the caller's rand([]) < 0.5 coin of psgd.py:1035 (nonzero = update U, else V). */

@@ -82,6 +82,8 @@ SIGNATURES = {
     "psgdk_lra_destroy": (C.c_int, [C.c_void_p]),
     "psgdk_lra_work_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "psgdk_lra_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psgdk_lra_set_gram_recurrence": (C.c_int, [C.c_void_p, C.c_int]),
+    "psgdk_lra_state_changed": (C.c_int, [C.c_void_p]),
     "psgdk_lra_update_whiten": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_float,
                                           C.c_float, C.c_float, C.c_void_p]),
     "psgdk_lra_precond_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -2302,6 +2302,11 @@ struct psgdk_lra {
     size_t sm_off = 0, v_off = 0, h_off = 0, qh_off = 0, iq_off = 0, diff_off = 0, y_off = 0, work_bytes = 0;
     int64_t row0 = 0;          // psgdk_lra_set_row_shard: this object's rows are rows [row0, row0 + N) of a larger, row-sharded preconditioner
     bool sharded = false;
+    // Gram recurrence (psgdk_lra_set_gram_recurrence; lra_gram_recur_kernel): the Grams of the current factors, carried from update to update
+    float* gst = nullptr;      // device: [UtU | VtV | VtU | rotated VtU of the update in flight], 4 x RM x RM fp32
+    int gram_every = 0;        // 0 = off: every update reads the factors for its Grams (psgd.py:1006 as written)
+    int gram_age = -1;         // updates since the Grams in gst were last read from the factors; -1 = gst is not valid
+    ~psgdk_lra() { if (gst) (void)hipFree(gst); }
 };
 
 extern "C" {
@@ -2336,6 +2341,23 @@ int psgdk_lra_work_bytes(const psgdk_lra* lra, size_t* work_bytes) {
 int psgdk_lra_bind(psgdk_lra* lra, void* U, void* V, void* d, float* Luvd, void* work) {
     if (!lra || !d || !Luvd || !work || (lra->r > 0 && (!U || !V))) return PSGDK_ERR_INVALID;
     lra->U = U; lra->V = V; lra->d = d; lra->Luvd = Luvd; lra->work = (unsigned char*)work;
+    lra->gram_age = -1;
+    return PSGDK_OK;
+}
+int psgdk_lra_set_gram_recurrence(psgdk_lra* lra, int every) {
+    if (!lra || every < 0) return PSGDK_ERR_INVALID;
+    if (every > 0 && lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;      // (the tuned rank classes only)
+    if (every > 0 && lra->r > 0 && !lra->gst) {
+        const size_t rm = (size_t)LRA_CB * lra_tpr_of_rank(lra->r);
+        HIPCHK(hipMalloc((void**)&lra->gst, 4 * rm * rm * sizeof(float)));
+    }
+    lra->gram_every = every;
+    lra->gram_age = -1;
+    return PSGDK_OK;
+}
+int psgdk_lra_state_changed(psgdk_lra* lra) {
+    if (!lra) return PSGDK_ERR_INVALID;
+    lra->gram_age = -1;
     return PSGDK_OK;
 }
 
@@ -2433,8 +2455,14 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
     // only the update's own slots: HSQ (||h||^2 of the last psgdk_lra_precond_grad, read by psgdk_flat_apply_clipped) and the apply's
     // reduction slots behind it survive an update that runs between precond_grad and the clipped parameter update
     // (update_preconditioner_first=False, psgd.py:1172-1183)
-    if (phase == 0)
+    if (phase == 0) {
         HIPCHK(hipMemsetAsync(sm, 0, (size_t)(tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ)) * 4, st));
+        HIPCHK(hipMemsetAsync(sm + (tpr == 1 ? LraCfg<1>::AB : (tpr == 2 ? LraCfg<2>::AB : LraCfg<4>::AB)), 0, 4, st));
+    }
+    // Gram recurrence: this update takes its Grams from the previous update's recurrence instead of reading U and V (row shards keep the pass:
+    // their sums run over the ranks)
+    const bool recur = L->gram_every > 0 && r > 0 && !L->sharded && L->gst != nullptr;
+    const bool grams_carried = recur && L->gram_age >= 0 && L->gram_age < L->gram_every;
     LRA_T(L, {
         T* Qh = (T*)(L->work + L->qh_off); T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
@@ -2442,13 +2470,15 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
         const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset, L->row0};
         switch (phase) {
         case 0:
-            if (r > 0) hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
+            if (grams_carried)      // UTU, VTV, VTU are the first three matrices of the scratch block, in gst's order
+                HIPCHK(hipMemcpyAsync(sm, L->gst, (size_t)3 * LraCfg<TPR>::MS * 4, hipMemcpyDeviceToDevice, st));
+            else if (r > 0) hipLaunchKernelGGL((lra_gram_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, N, r, sm);
             break;
         case 1:
             if (r > 0) {
                 if (shm_s1 > 64u * 1024u)
                     HIPCHK(hipFuncSetAttribute((const void*)lra_small1_kernel<T, TPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s1));
-                hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r);
+                hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r, recur ? L->gst + 3 * LraCfg<TPR>::MS : (float*)nullptr);
             }
             if constexpr (TPR == 1) {
                 hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
@@ -2472,6 +2502,11 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
             hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
             hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                                N, r, update_u ? 1 : 0, (const float*)sm);
+            if (recur) {      // the Grams of the factors as pass 5 leaves them, for the next update
+                hipLaunchKernelGGL((lra_gram_recur_kernel<T, TPR>), dim3(1), dim3(256), 0, st, (const float*)sm, (const float*)(L->gst + 3 * LraCfg<TPR>::MS),
+                                   L->gst, r, update_u ? 1 : 0);
+                L->gram_age = grams_carried ? L->gram_age + 1 : 1;
+            }
             break;
         }
     });

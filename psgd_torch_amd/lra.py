@@ -18,6 +18,9 @@ from . import _lib as L
 from .engine import _on_device
 
 
+GRAM_EVERY = 16      # updates between two true Gram passes (psgdk_lra_set_gram_recurrence); 0 = psgd.py:1006 as written, every update
+
+
 class _LraEngine:
     """One psgdk_lra object bound to (U, V, d, Luvd)."""
 
@@ -45,6 +48,13 @@ class _LraEngine:
         self.device = d.device if d.device.index is not None else torch.device("cuda", torch.cuda.current_device())
         L.check(self.lib.psgdk_lra_bind(self.h, U.data_ptr() if self.r else None, V.data_ptr() if self.r else None, d.data_ptr(),
                                         Luvd3.data_ptr(), self.work.data_ptr()), "lra_bind")
+        # The Grams of psgd.py:1006 are carried from update to update (include/psgdk.h: psgdk_lra_set_gram_recurrence) and re-read from the
+        # factors every GRAM_EVERY updates.  The engine writes U and V through raw pointers, which torch's version counters do not see: a
+        # counter that moved means SOMEBODY ELSE wrote the factor (a checkpoint copied in, a test poking it) -- then the Grams are re-read.
+        self.gram_every = GRAM_EVERY if 0 < self.r <= 64 else 0
+        if self.gram_every:
+            L.check(self.lib.psgdk_lra_set_gram_recurrence(self.h, self.gram_every), "lra_set_gram_recurrence")
+        self._versions = (U._version, V._version)
 
     def __del__(self):
         try:
@@ -72,6 +82,10 @@ class _LraEngine:
         g = g.contiguous()
         vn = v_noise.to(g.dtype).contiguous() if v_noise is not None else None
         self._k = (g, vn)
+        ver = (self.keep[0]._version, self.keep[1]._version)
+        if ver != self._versions:
+            self._versions = ver
+            L.check(self.lib.psgdk_lra_state_changed(self.h), "lra_state_changed")
         L.check(self.lib.psgdk_lra_update_whiten(self.h, g.data_ptr(), vn.data_ptr() if vn is not None else None, int(seed),
                                                  int(offset), int(bool(update_u)), float(lr), float(betaL), float(damping),
                                                  self._stream()), "lra_update_whiten")

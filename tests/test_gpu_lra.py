@@ -105,3 +105,69 @@ def test_lra_known_answer():
         lra.update_precond_lra_whiten(UVd, Luvd, g, lr=0.1 * (1 - it / iters) + 0.01, betaL=0.9, damping=0.0)
     h = lra.precond_grad_lra(UVd, g)
     assert relerr(h, v) < 0.15, relerr(h, v)
+
+
+@pytest.mark.parametrize("dn", ["fp32", "bf16"])
+@pytest.mark.parametrize("r", [10, 24, 40])
+def test_gram_recurrence_tracks_the_true_grams(dn, r, monkeypatch):
+    """Round 6: the Grams of psgd.py:1006 carried from update to update (lra_gram_recur_kernel) instead of read from the factors.  The same
+    sequence of updates (both branches of the U-or-V coin, replayed noise) with the recurrence on (re-read every 16 updates: never, here) and
+    off (psgd.py:1006 as written, every update): the factors, d and the Lipschitz estimates must agree to rounding -- fp32: 2e-5 after 8
+    updates; bf16: the two runs round differently, the bound is the golden tests' own (a few bf16 ulp of the factors)."""
+    from psgd_torch_amd import lra
+    dt = DT[dn]
+    N = 300_001
+    gen = torch.Generator().manual_seed(r)
+    U0 = torch.randn(N, r, generator=gen); U0 *= 0.1 ** 0.5 / torch.linalg.vector_norm(U0)
+    V0 = torch.randn(N, r, generator=gen); V0 *= 0.1 ** 0.5 / torch.linalg.vector_norm(V0)
+    gs = [torch.randn(N, 1, generator=gen) * torch.linspace(0.2, 3.0, N).reshape(N, 1) for _ in range(8)]
+    vs = [torch.randn(N, 1, generator=gen) for _ in range(8)]
+    coins = [0.1, 0.9, 0.9, 0.1, 0.1, 0.9, 0.1, 0.9]
+    runs = []
+    for every in (16, 0):
+        monkeypatch.setattr(lra, "GRAM_EVERY", every)
+        UVd = [U0.to(dt).to(DEV).contiguous(), V0.to(dt).to(DEV).contiguous(), torch.ones(N, 1, dtype=dt, device=DEV)]
+        Luvd = [torch.zeros([], dtype=torch.float32, device=DEV) for _ in range(3)]
+        for g, v, c in zip(gs, vs, coins):
+            lra.update_precond_lra_whiten(UVd, Luvd, g.to(dt).to(DEV), lr=0.2, betaL=0.9, damping=1e-9, v_noise=v.to(dt).to(DEV), coin=c)
+        assert UVd[2]._psgdk_lra.gram_every == every
+        h = lra.precond_grad_lra(UVd, gs[0].to(dt).to(DEV))
+        torch.cuda.synchronize()
+        runs.append(([x.float().cpu() for x in UVd] + [h.float().cpu()], [float(x) for x in Luvd]))
+    (a, la), (b, lb) = runs
+    tol = 2e-5 if dn == "fp32" else 2e-2
+    for nm, x, y in zip(("U", "V", "d", "h"), a, b):
+        assert torch.isfinite(x).all()
+        assert relerr(x, y) <= tol, (nm, relerr(x, y))
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= tol * abs(y), (la, lb)
+    # and the factors did move: the rotation + eight rank-1 steps are not a no-op
+    assert relerr(a[0], U0) > 1e-3
+
+
+def test_gram_recurrence_notices_a_factor_written_by_somebody_else():
+    """The engine cannot see a caller overwriting U between two updates; torch's version counter can: the Python host then has the Grams
+    re-read (psgdk_lra_state_changed).  Without that the carried Grams would describe the OLD factor."""
+    from psgd_torch_amd import lra
+    N, r = 100_000, 10
+    gen = torch.Generator().manual_seed(1)
+    mk = lambda: (torch.randn(N, r, generator=gen) * (0.1 ** 0.5 / (N * r) ** 0.5)).to(DEV)
+    g = torch.randn(N, 1, generator=gen).to(DEV)
+    v = torch.randn(N, 1, generator=gen).to(DEV)
+    U1, V1, U2 = mk(), mk(), mk()
+    res = []
+    for poke in (True, False):
+        UVd = [U1.clone(), V1.clone(), torch.ones(N, 1, device=DEV)]
+        Luvd = [torch.zeros([], device=DEV) for _ in range(3)]
+        if not poke:
+            UVd[0].copy_(3.0 * U2)                   # the reference run starts from the poked factor and reads its Grams as a first update does
+        else:
+            lra.update_precond_lra_whiten(UVd, Luvd, g, v_noise=v, coin=0.1)      # Grams now carried ...
+            UVd[0].copy_(3.0 * U2); UVd[1].copy_(V1); UVd[2].fill_(1.0)           # ... and the caller replaces the state
+            for x in Luvd:
+                x.zero_()
+        lra.update_precond_lra_whiten(UVd, Luvd, g, v_noise=v, coin=0.9)
+        torch.cuda.synchronize()
+        res.append([x.cpu() for x in UVd])
+    for x, y in zip(*res):
+        assert relerr(x, y) <= 1e-6, relerr(x, y)
