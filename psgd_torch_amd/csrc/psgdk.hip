@@ -216,7 +216,7 @@ void launch_stage(psgdk_plan* p, const Stage& s, hipStream_t st, const GemmUpdAr
         }
         e0 = p->prof_ev[p->prof_used].first; e1 = p->prof_ev[p->prof_used].second;
         if (p->prof_fused.size() <= p->prof_used) p->prof_fused.resize(p->prof_used + 1);
-        p->prof_fused[p->prof_used] = upd ? 1 : 0;
+        p->prof_fused[p->prof_used] = (upd && upd->lr > 0.f) ? 1 : 0;
         ++p->prof_used;
     }
     const GemmUpdArgs u = upd ? *upd : GemmUpdArgs{0.f, 1.f, 0.f, 0, 0, 0};
@@ -1245,7 +1245,15 @@ static int update_whiten_family(psgdk_plan* plan, int variant, int source, float
                                              P->state, P->work, source == PSGDK_SRC_GRAD ? 1 : 0, damping, seed, offset));
         // Pg = (kron Q^T Q) X and the mode Grams (psgd.py:403-405)
         if ((rc = ensure_P(P, st))) return rc;
-        launch_stage(P, P->g_upd_a, st);
+        {
+            // the persistent 256 x 256 launch of the update's first product: workgroups that walk one tile fewer start up to ~0.9 tile times
+            // late (GemmUpdArgs::stagger; a tile of K columns takes ~44 K ns): their output bursts (Pg^T, 128 KiB per tile) fall between the
+            // others'.  GPT-2-small: -10 us per step (r6j); psgdk_test_fuse_mode(.., 0) switches it off for A/B runs
+            int kmax = 0;
+            if (P->g_upd_a.big) for (const GemmProblem& g : P->g_upd_a.probs) kmax = std::max(kmax, g.K);
+            GemmUpdArgs sa{0.f, 1.f, 0.f, 0, P->fuse_stagger == 0 ? 0 : std::min(4 * kmax, 16000), 0};
+            launch_stage(P, P->g_upd_a, st, sa.stagger ? &sa : nullptr);
+        }
         launch_stage(P, P->g_upd_b, st);
         if (P->n_tiles_diag)
             DISPATCH_T(P, hipLaunchKernelGGL(diag_tensor_kernel<T>, dim3(P->n_tiles_diag), dim3(256), 0, st, P->d_td, P->d_dd,
@@ -1737,7 +1745,7 @@ int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, 
     if ((rc = ensure_P(P, st))) return rc;
     // stagger: workgroups that walk one tile fewer start up to ~one tile time late (measured on GPT-2-small, K = 768: 4000 ticks of 10 ns:
     // 389 -> 375 us per fused apply; scaled with K for other widths; psgdk_test_fuse_mode overrides)
-    int stagger = P->fuse_stagger;
+    int stagger = P->fuse_stagger > 0 ? (P->fuse_stagger & 0xfffff) : P->fuse_stagger;
     if (stagger < 0) {
         int kmax = 0;
         for (const GemmProblem& g : P->f_app_a.probs) kmax = std::max(kmax, g.K);
