@@ -221,6 +221,8 @@ def bench_lra(args):
            "dtype": "bf16" if args.bf16 else "fp32", "data": "synthetic",
            "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, {'bf16' if args.bf16 else 'fp32'}: update_precond_lra_whiten + precond_grad_lra",
                       "rank": r,
+                      "true_gram_passes_in_timed_region": (len([k for k in range(args.warmup, args.warmup + args.steps) if k % lra.GRAM_EVERY == 0])
+                                                           if (lra.GRAM_EVERY and r <= 64) else args.steps),
                       "gram_recurrence": (f"the Grams of psgd.py:1006 carried from update to update (r x r recurrence), the factors re-read for them every "
                                           f"{lra.GRAM_EVERY} updates: 13 + 2/{lra.GRAM_EVERY} matrix passes per update + apply instead of 15; `achieved` prices the "
                                           "SURVEY's 15 (algorithmic bytes of the path as the reference defines it), `moved_gbs` what the kernels moved")
@@ -308,7 +310,8 @@ def secondary_workloads():
     the workload's own roofline fraction, so that the driver's record carries all of them.  Not part of `value`."""
     import subprocess
     res = {}
-    for name, extra, steps in (("lenet5", [], 200), ("vit-b-lra", [], 10), ("vit-b-lra-bf16", ["--bf16"], 10), ("gpt2-medium", [], 10)):
+    # (LRA: 16 timed steps after 5 = one true Gram pass among them -- lra.GRAM_EVERY = 16 -- so the figure carries the recurrence's amortised cost)
+    for name, extra, steps in (("lenet5", [], 200), ("vit-b-lra", [], 16), ("vit-b-lra-bf16", ["--bf16"], 16), ("gpt2-medium", [], 10)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name.replace("-bf16", ""), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline",
                "--no-secondary", "--no-apply-only", "--no-peaks"] + extra
         t0 = time.perf_counter()

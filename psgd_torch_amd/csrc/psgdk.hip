@@ -2370,11 +2370,16 @@ int psgdk_lra_state_changed(psgdk_lra* lra) {
 }
 
 // element type x rank class (threads per row: 1, 2, 4 for ranks up to 16, 32, 64)
-#define LRA_TPR_(tpr_, ...) do { if ((tpr_) == 1) { constexpr int TPR = 1; __VA_ARGS__; } else if ((tpr_) == 2) { constexpr int TPR = 2; __VA_ARGS__; } \
-                                 else { constexpr int TPR = 4; __VA_ARGS__; } } while (0)
-#define LRA_T(L, ...) do { const int tpr_ = lra_tpr_of_rank((L)->r);                                        \
-                           if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; LRA_TPR_(tpr_, __VA_ARGS__); }  \
-                           else { typedef float T; LRA_TPR_(tpr_, __VA_ARGS__); } } while (0)
+// (RC: the columns a thread's register arrays hold -- r rounded up to a multiple of 4 in the one-thread-per-row class, so that the reference's
+//  default rank 10 carries 12-wide arrays instead of 16-wide ones: the row passes are bound by what their registers let them keep in flight)
+#define LRA_TPR_(tpr_, rc_, ...) do { if ((tpr_) == 1) { constexpr int TPR = 1;                                                                  \
+                                          if ((rc_) <= 4) { constexpr int RC = 4; __VA_ARGS__; } else if ((rc_) <= 8) { constexpr int RC = 8; __VA_ARGS__; } \
+                                          else if ((rc_) <= 12) { constexpr int RC = 12; __VA_ARGS__; } else { constexpr int RC = 16; __VA_ARGS__; } }       \
+                                      else if ((tpr_) == 2) { constexpr int TPR = 2; constexpr int RC = LRA_CB; __VA_ARGS__; }                     \
+                                      else { constexpr int TPR = 4; constexpr int RC = LRA_CB; __VA_ARGS__; } } while (0)
+#define LRA_T(L, ...) do { const int tpr_ = lra_tpr_of_rank((L)->r); const int rc_ = (L)->r;                      \
+                           if ((L)->dtype == PSGDK_BF16) { typedef bf16_t T; LRA_TPR_(tpr_, rc_, __VA_ARGS__); }  \
+                           else { typedef float T; LRA_TPR_(tpr_, rc_, __VA_ARGS__); } } while (0)
 
 // launch geometry of the LRA row passes: dynamic LDS for `mats` row buffers of (256 / tpr) x r floats (+ `fixed` bytes of
 // static LDS), and as many workgroups as are resident at once (grid-stride loops; <= 8 workgroups of 4 waves per CU)
@@ -2489,7 +2494,7 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
                 hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r, recur ? L->gst + 3 * LraCfg<TPR>::MS : (float*)nullptr);
             }
             if constexpr (TPR == 1) {
-                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
+                hipLaunchKernelGGL((lra_rotate_kernel<T, TPR, RC>), dim3(gbr), dim3(LRA_THREADS), shmr, st, U, V, (const T*)d, vh, N, r, sm);
             } else {      // wider rank classes: the rotation on the fp32 matrix cores
                 const int rows_m = LRA_ROWS / TPR;
                 const unsigned gm = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + rows_m - 1) / rows_m, 256 * 3));
@@ -2498,17 +2503,17 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
             break;
         case 2:
             hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-            hipLaunchKernelGGL((lra_pass3_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+            hipLaunchKernelGGL((lra_pass3_kernel<T, TPR, RC>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                                Qh, iq, N, r, sm);
             break;
         case 3:
             hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
-            hipLaunchKernelGGL((lra_pass4_kernel<T, TPR>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
+            hipLaunchKernelGGL((lra_pass4_kernel<T, TPR, RC>), dim3(gb2), dim3(LRA_THREADS), shm2, st, (const T*)U, (const T*)V, (const T*)d, vh,
                                (const T*)Qh, (const T*)iq, diff, N, r, sm);
             break;
         default:
             hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
-            hipLaunchKernelGGL((lra_pass5_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
+            hipLaunchKernelGGL((lra_pass5_kernel<T, TPR, RC>), dim3(gb1), dim3(LRA_THREADS), shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff,
                                N, r, update_u ? 1 : 0, (const float*)sm);
             if (recur) {      // the Grams of the factors as pass 5 leaves them, for the next update
                 hipLaunchKernelGGL((lra_gram_recur_kernel<T, TPR>), dim3(1), dim3(256), 0, st, (const float*)sm, (const float*)(L->gst + 3 * LraCfg<TPR>::MS),
@@ -2529,7 +2534,7 @@ static int lra_apply_phase_t(psgdk_lra* L, int phase, const void* g, void* out, 
     LRA_T(L, {
         if (phase == 0) HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
         T* y = (T*)(L->work + L->y_off);
-        hipLaunchKernelGGL((lra_apply_kernel<T, TPR>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
+        hipLaunchKernelGGL((lra_apply_kernel<T, TPR, RC>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                            (const T*)g, y, (T*)out, L->N, L->r, phase, sm);
     });
     HIPCHK(hipGetLastError());
