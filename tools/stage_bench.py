@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 eng = next(iter(opt._buckets.values())).engine
 lib = _lib.lib()
 names = ["upd_a (X P -> Pg^T)", "app_a (ema P -> h)", "gram", "qupd", "rq", "rrq", "P = Q^T Q", "upd_b", "app_b"]
-vnames = {0: "as bound", 2: "1 wg/tile", 3: "128x128", 4: "256x256", 5: "no sums", 6: "no sums/scale", 7: "no stores", 8: "no epilogue", 14: "128x128 (forced)", 20: "8-wave", 21: "4-wave", 22: "8-wave no epi", 23: "4-wave no epi", 24: "8-wave no st", 25: "4-wave no st", 26: "8-wave reg st", 27: "4-wave reg st", 56: "reg stores", 30: "ping-pong", 31: "ping-pong no epi", 32: "ping-pong no epi/DMA"}
+vnames = {0: "as bound", 2: "1 wg/tile", 3: "128x128", 4: "256x256", 5: "no sums", 6: "no sums/scale", 7: "no stores", 8: "no epilogue", 14: "128x128 (forced)", 20: "8-wave", 21: "4-wave", 22: "8-wave no epi", 23: "4-wave no epi", 24: "8-wave no st", 25: "4-wave no st", 26: "8-wave reg st", 27: "4-wave reg st", 56: "reg stores", 60: "ring", 61: "ring no epi", 30: "ping-pong", 31: "ping-pong no epi", 32: "ping-pong no epi/DMA"}
 for rnd in range(2):
     for which, nm in list(enumerate(names))[:9]:
         out = []
