@@ -1128,7 +1128,8 @@ static int nlb_plan_coop(psgdk_plan* P) {
     P->nlb_lds = (unsigned)(32 * ((size_t)P->max_dp * P->esz + 16) + 8 * 32 * (32 * P->esz + 16));
     for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24>, (const void*)nlb_coop_kernel<float, 2, 24>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 4>, (const void*)nlb_coop_kernel<float, 1, 8>,
-                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>})
+                          (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 4, true>, (const void*)nlb_coop_kernel<float, 1, 8, true>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
@@ -1137,8 +1138,8 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
                    int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0, bool stamps = false) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
-        if (stamps && P->nlb_small) return PSGDK_ERR_UNSUPPORTED;      // (the instrumented instantiation exists for the general shape only)
-        const void* k = stamps ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>)
+        const void* k = stamps ? (P->nlb_small ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 1, 4, true> : (const void*)nlb_coop_kernel<float, 1, 8, true>)
+                                               : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>))
                       : P->nlb_small ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
                                : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
