@@ -308,6 +308,9 @@ int psgdk_lra_phase_segments(const psgdk_lra* lra, int kind, int phase, int* n_s
 #define PSGDK_INFO_BALNORM_OFFSET 5  /* byte offset in the WORK arena of the balancing slots of psgdk_balance_phase */
 #define PSGDK_INFO_UPDATE_FUSED 6    /* how many tensors' parameter updates ran inside a GEMM epilogue in the last psgdk_precond_grad_apply
                                         (0: it took the two-call route, or the last h came from psgdk_precond_grad) */
+#define PSGDK_INFO_NLB_MEMBER_COLS 7  /* columns of a factor one workgroup of the cooperative bound covers: 256, or 128 where the plan is small
+                                        enough for twice the members (round 6), or 128 with one workgroup per factor (widest factor <= 128);
+                                        0 without a cooperative launch */
 int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
 
 /* ---- row shards: the sharded (multi-GPU) path's split of a DOMINANT tensor (new; the reference only replicates -- SURVEY 8e.  GPT-2's

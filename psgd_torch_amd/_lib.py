@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE, PSGDK_ERR_NLB_TIMEOUT = 0, 1, 2, 3, 4, 5
 INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM, INFO_HSUMSQ_OFFSET, INFO_BALNORM_OFFSET, INFO_UPDATE_FUSED = 0, 1, 2, 3, 4, 5, 6
+INFO_NLB_MEMBER_COLS = 7
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6

@@ -72,6 +72,8 @@ struct psgdk_plan {
     int max_dp = 0;
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
     bool nlb_small = false;           // ... in its instantiation for plans whose widest factor is <= 128 (one workgroup per factor, 16 columns per wave)
+    bool nlb_narrow = false;          // ... with 128 columns of A per member instead of 256 (round 6): plans with few wide factors -- a rank's share
+                                      //     of a sharded job, a model of a few layers -- whose 2 x as many members still fit the CUs
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
     unsigned long long* d_nlb_ts = nullptr;   // psgdk_test_nlb_stamps: NLB_TS_SLOTS words per workgroup (its address sits after the job table)
     // error word of the cooperative kernels: host-mapped pinned memory, so that the host can look at it WITHOUT synchronising
@@ -1087,20 +1089,32 @@ static int nlb_plan_coop(psgdk_plan* P) {
     // work on a 128-wide factor) and as many K steps of registers as such a factor has -- the general instantiation loaded 24 K steps
     // (sized for 768) of which 16 were dead re-reads: 10.5 of the 39 us a bound took on LeNet5's plan (profiles/r04_a)
     P->nlb_small = P->max_dp <= 128;
-    const int cols_per_wg = P->nlb_small ? 128 : 256;
-    for (int f : order) {
-        const int S = (P->dn[f].dp + cols_per_wg - 1) / cols_per_wg;
-        size_t best = 0;
-        for (size_t x = 1; x < 8; ++x) if (xcd[x].size() < xcd[best].size()) best = x;
-        for (int m = 0; m < S; ++m) xcd[best].push_back(NlbJob{f, m, S, 0});
-    }
-    size_t len = 0;
-    for (auto& l : xcd) len = std::max(len, l.size());
+    P->nlb_narrow = false;
     // one workgroup per CU (512 threads, ~250 VGPRs): all siblings are resident only if an XCD's share fits its CUs
     int dev = 0, cus = 0;
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus < 8 || len > (size_t)(cus / 8)) return PSGDK_OK;
+    if (cus < 8) return PSGDK_OK;
+    size_t len = 0;
+    // Members of 128 columns where the plan is small enough for twice the members (a slab of A is half as long to pull into registers, a
+    // product half as many matrix instructions, a published piece half the stores: tools/nlb_stamps.py), members of 256 otherwise.
+    // PSGDK_NLB_NARROW=0 keeps the wide members (the GPU suite compares the two on one plan).
+    const char* env_narrow = getenv("PSGDK_NLB_NARROW");
+    for (int cols_per_wg : {128, 256}) {
+        if (cols_per_wg == 128 && !P->nlb_small && env_narrow && env_narrow[0] == '0') continue;
+        for (auto& l : xcd) l.clear();
+        for (int f : order) {
+            const int S = (P->dn[f].dp + cols_per_wg - 1) / cols_per_wg;
+            size_t best = 0;
+            for (size_t x = 1; x < 8; ++x) if (xcd[x].size() < xcd[best].size()) best = x;
+            for (int m = 0; m < S; ++m) xcd[best].push_back(NlbJob{f, m, S, 0});
+        }
+        len = 0;
+        for (auto& l : xcd) len = std::max(len, l.size());
+        if (len <= (size_t)(cus / 8)) { P->nlb_narrow = cols_per_wg == 128 && !P->nlb_small; break; }
+        if (P->nlb_small) break;
+    }
+    if (len > (size_t)(cus / 8)) return PSGDK_OK;
     std::vector<NlbJob> jobs(8 * len, NlbJob{-1, 0, 0, 0});
     for (size_t x = 0; x < 8; ++x)
         for (size_t k = 0; k < xcd[x].size(); ++k) jobs[k * 8 + x] = xcd[x][k];
@@ -1129,7 +1143,9 @@ static int nlb_plan_coop(psgdk_plan* P) {
     for (const void* k : {(const void*)nlb_coop_kernel<bf16_t, 2, 24>, (const void*)nlb_coop_kernel<float, 2, 24>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 4>, (const void*)nlb_coop_kernel<float, 1, 8>,
                           (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
-                          (const void*)nlb_coop_kernel<bf16_t, 1, 4, true>, (const void*)nlb_coop_kernel<float, 1, 8, true>})
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 4, true>, (const void*)nlb_coop_kernel<float, 1, 8, true>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 24>, (const void*)nlb_coop_kernel<float, 1, 24>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 24, true>, (const void*)nlb_coop_kernel<float, 1, 24, true>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
@@ -1138,10 +1154,13 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
                    int add_c, int pro_iter, hipStream_t st, int route = -1, int fault = 0, bool stamps = false) {
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
-        const void* k = stamps ? (P->nlb_small ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 1, 4, true> : (const void*)nlb_coop_kernel<float, 1, 8, true>)
-                                               : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>))
-                      : P->nlb_small ? (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
-                               : (P->dtype == PSGDK_BF16 ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
+        const bool bf = P->dtype == PSGDK_BF16;
+        const void* k = stamps ? (P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4, true> : (const void*)nlb_coop_kernel<float, 1, 8, true>)
+                                  : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24, true> : (const void*)nlb_coop_kernel<float, 1, 24, true>)
+                                                  : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>))
+                      : P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
+                      : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24> : (const void*)nlb_coop_kernel<float, 1, 24>)
+                                      : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;
         unsigned char* state = P->state; unsigned char* work = P->work;
         void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
@@ -1899,6 +1918,7 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
         case PSGDK_INFO_HSUMSQ_OFFSET: *value = (int64_t)plan->hsumsq_off; return PSGDK_OK;
         case PSGDK_INFO_BALNORM_OFFSET: *value = (int64_t)plan->balnorm_off; return PSGDK_OK;
         case PSGDK_INFO_UPDATE_FUSED: *value = plan->h_fused ? (int64_t)plan->n_fix : 0; return PSGDK_OK;
+        case PSGDK_INFO_NLB_MEMBER_COLS: *value = !plan->nlb_coop ? 0 : ((plan->nlb_small || plan->nlb_narrow) ? 128 : 256); return PSGDK_OK;
     }
     return PSGDK_ERR_INVALID;
 }

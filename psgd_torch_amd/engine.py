@@ -455,7 +455,7 @@ class KronEngine:
         out = {}
         for name, code in (("nlb_coop", L.INFO_NLB_COOP), ("nlb_fallbacks", L.INFO_NLB_FALLBACKS),
                            ("dense_factors", L.INFO_DENSE_FACTORS), ("max_dense_dim", L.INFO_MAX_DENSE_DIM),
-                           ("update_fused", L.INFO_UPDATE_FUSED)):
+                           ("update_fused", L.INFO_UPDATE_FUSED), ("nlb_member_cols", L.INFO_NLB_MEMBER_COLS)):
             v = C.c_int64()
             L.check(self.lib.psgdk_plan_info(self._plan, code, C.byref(v)), "plan_info")
             out[name] = int(v.value)
