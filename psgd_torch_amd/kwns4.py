@@ -11,7 +11,7 @@ What is different, on purpose:
   * `shard_state=True` (new; the reference only replicates): every rank owns a cost-balanced subset of
     the parameters, preconditions only those, and the clipped preconditioned gradients are exchanged by all-gather
     (RCCL over xGMI); every rank then applies the identical parameter update.  The tensors are worked off in
-    `shard_chunks` (default 2) cost-balanced chunks, each with its own exchange buffer: chunk c's asynchronous, in-place
+    `shard_chunks` cost-balanced chunks (default: 1 or 2 by the exchange model, `auto_shard_chunks`), each with its own exchange buffer: chunk c's asynchronous, in-place
     all-gather travels while chunk c + 1 is preconditioned, and the parameter updates follow chunk by chunk as the
     gathers land -- on a step this short the fabric, not the arithmetic, is the critical path (DESIGN.md section 6);
   * (round 4) a DOMINANT matrix whose dim-0 factor is diagonal and whose dim-1 factor is dense (GPT-2's tied embedding) is SPLIT BY ROWS
@@ -79,6 +79,17 @@ class _Works:
 # exchange it hides takes longer than that: at 8 ranks a GPT-2-small step receives 218 MB (~0.7 ms at 300 GB/s), so two chunks hide what
 # one more plan costs, four never do (rounds 2-3 defaulted to 4 without this measurement).  bench.py's probe times 1, 2 and 4.
 DEFAULT_SHARD_CHUNKS = 2
+
+
+def auto_shard_chunks(numel: int, esize: int, world: int) -> int:
+    """The chunk count of an optimizer that named none (round 6): ONE plan per rank unless the exchange model says a second one pays.
+    A second chunk hides (at best) the first chunk's half of the exchange under its own arithmetic and costs ~0.3 ms of launches that do
+    not shrink (above).  Every rank receives numel * esize / world bytes from each peer, one xGMI link per peer, all links at once:
+    t = bytes per peer / link rate, priced at 77 GB/s per direction (half of the link's 153 GB/s: unmeasured on hardware, like everything
+    about N > 1 here).  GPT-2-small at 8 ranks: 31 MB per peer = 0.40 ms -> one chunk; GPT-2-medium at 8: 89 MB = 1.15 ms -> two; any model
+    at 2 ranks with >= 93 M elements -> two.  bench.py --parallelism auto still times 1, 2 and 4 chunks on the fabric it runs on."""
+    t_exchange = numel * esize / max(world, 1) / 77e9
+    return DEFAULT_SHARD_CHUNKS if 0.5 * t_exchange > 0.3e-3 else 1
 
 
 class _Bucket:
@@ -175,7 +186,8 @@ class KWNS4(torch.optim.Optimizer):
         self.shard_state = bool(shard_state) and self.world > 1
         # sharded mode: the tensors of a bucket are worked off in this many cost-balanced chunks, each with its own exchange
         # buffer, so that chunk c's all-gather travels while chunk c + 1 is preconditioned (1 = one exchange)
-        self._shard_chunks = max(1, int(shard_chunks if shard_chunks is not None else DEFAULT_SHARD_CHUNKS)) if self.shard_state else 1
+        # (None: decided by auto_shard_chunks when the first bucket is built -- 0 until then)
+        self._shard_chunks = (max(1, int(shard_chunks)) if shard_chunks is not None else 0) if self.shard_state else 1
         self._shard_chunks_explicit = shard_chunks is not None      # (a checkpoint may bring its own count to an optimizer that named none)
         # how a chunk's clipped preconditioned gradients travel: "all_gather" (one collective; RCCL picks the algorithm) or "p2p"
         # (every rank sends its segment to each peer directly and receives theirs: 2 (N - 1) grouped point-to-point operations, all
@@ -272,6 +284,9 @@ class KWNS4(torch.optim.Optimizer):
                 cand = {i: bl for i, bl in cand.items() if self._grad_of(plist[i]).dim() >= 1 and self._grad_of(plist[i]).shape[0] == shapes[i][0]
                         and self._grad_of(plist[i]).numel() == shapes[i][0] * shapes[i][1]}
                 self._rowsplit[key] = {pos[id(plist[i])]: [tuple(b) for b in blocks] for i, blocks in cand.items()}
+        if self._shard_chunks == 0:      # no count named: from the exchange model, the same on every rank (all see the same parameter list)
+            esize = torch.empty((), dtype=group["preconditioner_dtype"] or g0.dtype).element_size()
+            self._shard_chunks = auto_shard_chunks(sum(self._grad_of(p).numel() for p in plist), esize, self.world)
         if self._shard_chunks <= 1:
             return self._buckets_for_key(gi, group, plist, key)
         ch = self._chunks.get(key)           # {position in the group: chunk}; part of the checkpoint

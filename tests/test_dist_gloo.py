@@ -4,6 +4,7 @@ The compute engine is the TEST-ONLY OracleEngine (tests/oracle_engine.py) inject
 so this exercises exactly the host logic the GPU run uses: deterministic cost-balanced ownership, per-rank engines
 over owned tensors only, the single all-gather exchange of the clipped preconditioned gradients, identical parameter
 update on every rank, gate streams in lock-step.  The sharded result must equal the single-process result."""
+import math
 import os
 import socket
 import tempfile
@@ -109,9 +110,12 @@ def test_sharded_equals_replicated(kw):
         r1 = torch.load(os.path.join(d, "r1.pt"))
     if not kw.get("missing"):
         assert sum(r0["owned"]) + sum(r1["owned"]) == len(SHAPES) and min(sum(r0["owned"]), sum(r1["owned"])) >= 1
-        # (default: 2 chunks per bucket, each with its own exchange; shard_chunks=1: one)
-        from psgd_torch_amd.kwns4 import DEFAULT_SHARD_CHUNKS
-        assert r0["n_buckets"] == min(kw.get("shard_chunks", DEFAULT_SHARD_CHUNKS), len(SHAPES)), r0["n_buckets"]
+        # (default: 1 or 2 chunks per bucket by the exchange model -- one for a model of this size --, each with its own exchange)
+        from psgd_torch_amd.kwns4 import DEFAULT_SHARD_CHUNKS, auto_shard_chunks
+        assert auto_shard_chunks(sum(math.prod(s) for s in SHAPES), 4, 2) == 1
+        assert auto_shard_chunks(124_475_904, 2, 8) == 1 and auto_shard_chunks(354_871_296, 2, 8) == DEFAULT_SHARD_CHUNKS == 2
+        assert auto_shard_chunks(124_475_904, 2, 2) == 2
+        assert r0["n_buckets"] == min(kw.get("shard_chunks", 1), len(SHAPES)), r0["n_buckets"]
         # both exchange forms are exercised: one chunk over two ranks is balanced (the collective over equal segments), the small
         # chunks of a four-chunk setting are mostly padding (exact-size point-to-point exchange)
         if kw.get("shard_chunks") == 1 and kw.get("shard_exchange") != "p2p":
