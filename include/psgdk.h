@@ -39,7 +39,7 @@ extern "C" {
 enum {
     PSGDK_OK = 0,
     PSGDK_ERR_INVALID = 1,     /* bad argument (mirrors the reference's assert/ValueError sites) */
-    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built (LRA rank > 1024; row shards outside the default geometry) */
+    PSGDK_ERR_UNSUPPORTED = 2, /* valid in the reference, not built (LRA rank > 1024; row shards outside the Q0.5EQ1.5 / QEQ / QUAD geometries) */
     PSGDK_ERR_HIP = 3,         /* a HIP runtime call failed; see psgdk_last_hip_error() */
     PSGDK_ERR_STATE = 4,       /* call order violated (e.g. arenas not bound) */
     PSGDK_ERR_NLB_TIMEOUT = 5  /* returned ONCE by the first psgdk_update_precond_* call after a cooperative norm-bound launch of an
@@ -330,7 +330,9 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value);
  *     balance flags of shards;
  *   - psgdk_precond_grad leaves the shard's OWN sum of h^2 at PSGDK_INFO_HSUMSQ_OFFSET + 4 t: the caller sums it over the members before
  *     psgdk_export_precond_grad / psgdk_apply_update clip.
- * Q0.5EQ1.5 geometry only; before psgdk_plan_bind.  The one-call psgdk_update_precond_q0p5eq1p5 refuses a plan with shards. */
+ * Geometries Q0.5EQ1.5, QEQ and QUAD (round 6: the three that share Pg, the mode Grams and the norm-bound step -- psgd.py:394-419, 367-391,
+ * 455-483; begin / finish dispatch on the plan's geometry); the others return PSGDK_ERR_UNSUPPORTED.  Before psgdk_plan_bind.  The one-call
+ * psgdk_update_precond_* refuse a plan with shards. */
 int psgdk_plan_set_row_shard(psgdk_plan* plan, int t, int64_t global_rows, int64_t row0, int member, int members);
 int psgdk_plan_exchange_bytes(const psgdk_plan* plan, size_t* record_bytes);
 int psgdk_update_precond_begin(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,

@@ -512,7 +512,9 @@ int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
 int psgdk_plan_set_row_shard(psgdk_plan* plan, int t, int64_t global_rows, int64_t row0, int member, int members) {
     if (!plan || t < 0 || t >= plan->n_tensors || members < 2 || member < 0 || member >= members) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
-    if (plan->geometry != PSGDK_GEOM_Q0P5EQ1P5) return PSGDK_ERR_UNSUPPORTED;
+    // the three geometries that share Pg, the mode Grams and the norm-bound step size (update_whiten_family): for all of them the rows of a
+    // [diagonal, dense] matrix are independent given the dense factor, whose mode Gram is the only sum over the row blocks
+    if (plan->geometry != PSGDK_GEOM_Q0P5EQ1P5 && plan->geometry != PSGDK_GEOM_QEQ && plan->geometry != PSGDK_GEOM_QUAD) return PSGDK_ERR_UNSUPPORTED;
     TensorDesc& D = plan->td[t];
     // a row block of a matrix with a diagonal factor on dim 0 and a dense one on dim 1, held as it is (rows contiguous in the caller's
     // tensor): the structure init_kron gives the WHOLE tensor must also be what the block got from its own shape (the host checks that
@@ -1437,11 +1439,13 @@ int psgdk_update_precond_q0p5eq1p5(psgdk_plan* plan, int source, float lr, float
 }
 int psgdk_update_precond_begin(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
                                uint64_t offset, void* exchange, void* stream) {
-    return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, nullptr, stream, 0, exchange);
+    if (!plan) return PSGDK_ERR_INVALID;
+    return update_whiten_family(plan, plan->geometry, source, lr, betaL, damping, noise, seed, offset, nullptr, stream, 0, exchange);
 }
 int psgdk_update_precond_finish(psgdk_plan* plan, int source, float lr, float betaL, float damping, const psgdk_noise* noise, uint64_t seed,
                                 uint64_t offset, const void* exchange, const uint8_t* balance_mask, void* stream) {
-    return update_whiten_family(plan, PSGDK_GEOM_Q0P5EQ1P5, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream, 1,
+    if (!plan) return PSGDK_ERR_INVALID;
+    return update_whiten_family(plan, plan->geometry, source, lr, betaL, damping, noise, seed, offset, balance_mask, stream, 1,
                                 (void*)exchange);
 }
 // balance_kron_precond (psgd.py:266-275) of ROW SHARDS in two calls: phase 0 leaves max |q| of the shard's two factors in the plan's

@@ -213,7 +213,8 @@ class KWNS4(torch.optim.Optimizer):
         # key is first seen (cost model, deterministic on every rank), part of the checkpoint
         # shard_split_rows: True = tensors that cost more than half a rank's fair share of their group; a float = that fraction (0.0:
         # every tensor of the right structure); False = none
-        self._split_rows = shard_split_rows is not False and self.shard_state and self.dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5")
+        # (the geometries whose update is the default one's up to the dense factor's own step: psgdk_plan_set_row_shard takes these three)
+        self._split_rows = shard_split_rows is not False and self.shard_state and self.dQ in ("Q0.5EQ1.5", "Q0p5EQ1p5", "QEQ", "QUAD")
         self._split_rows_threshold = 0.5 if shard_split_rows is True else float(shard_split_rows or 0.0)
         self._rowsplit = {}
 

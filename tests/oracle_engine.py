@@ -75,7 +75,7 @@ class OracleEngine:
         self.hsumsq = torch.zeros(self.n, dtype=torch.float32)
         self.xchg = None
         if self.row_shards:
-            assert geometry in ("Q0.5EQ1.5", "Q0p5EQ1p5")
+            assert geometry in ("Q0.5EQ1.5", "Q0p5EQ1p5", "QEQ", "QUAD")
             members = next(iter(self.row_shards.values()))[3]
             self.member = next(iter(self.row_shards.values()))[2]
             # one record per member: per shard [cols x cols fp32 partial Gram][64 fp32 scalars], like the HIP engine's
@@ -158,17 +158,30 @@ class OracleEngine:
                 term1 = term1 + self._rec(m, k)[0]
             term1 = term1.to(Q[1].dtype)
             mx = torch.max(torch.stack([self._rec(m, k)[1][0] for m in range(members)])).to(Q[0].dtype)
-            # the diagonal factor (psgd.py:406-410) on this member's rows, with the WHOLE matrix's maximum and element count
+            quad = self.geometry == "QUAD"
+            # the diagonal factor (psgd.py:406-410; QEQ :380-384, QUAD :466-471) on this member's rows, with the WHOLE matrix's maximum and
+            # element count
             term2 = total_numel / grow
             ell = mx + term2
             Lq[0].copy_(torch.max(betaL * Lq[0] + (1 - betaL) * ell, ell))
-            Q[0].mul_(1 - lr / Lq[0] * (t_diag - term2))
-            # the dense factor (psgd.py:411-416), replicated: every member computes the same
+            if quad:
+                gain = 1 - lr / 2 / Lq[0] * (t_diag - term2)
+                Q[0].mul_(gain * gain)
+            else:
+                Q[0].mul_(1 - lr / Lq[0] * (t_diag - term2))
+            # the dense factor (psgd.py:411-416; QEQ :385-388, QUAD :472-481), replicated: every member computes the same
             term2 = total_numel / Q[1].shape[0]
             ell = orc.norm_lower_bound_spd(term1, nz.spd[1]) + term2
             Lq[1].copy_(torch.max(betaL * Lq[1] + (1 - betaL) * ell, ell))
-            Q[1].sub_(lr / Lq[1] * (term1 @ Q[1] - term2 * Q[1]))
-            orc.procrustes_step2(Q[1], nz.skh[1])
+            if self.geometry == "QEQ":
+                Q[1].sub_(lr / Lq[1] * (Q[1] @ term1 - Q[1] * term2))
+            elif quad:
+                p_ = Q[1] - lr / 2 / Lq[1] * (term1 @ Q[1] - term2 * Q[1])
+                p_ = p_ - lr / 2 / Lq[1] * (p_ @ term1 - p_ * term2)
+                Q[1].copy_((p_ + p_.t()) / 2)
+            else:
+                Q[1].sub_(lr / Lq[1] * (term1 @ Q[1] - term2 * Q[1]))
+                orc.procrustes_step2(Q[1], nz.skh[1])
         self._pending = {}
         self.update_precond(source, lr, betaL, damping, seed=seed, offset=offset, balance_mask=balance_mask, _skip=set(self.row_shards))
 

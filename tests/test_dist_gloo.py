@@ -192,7 +192,8 @@ def _row_worker(rank, world, port, outdir, kw, shapes, steps):
 
 @pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(shard_chunks=1, update_preconditioner_first=False, whiten_grad=True)),
                                       (3, dict(preconditioner_update_probability=0.6, momentum=0.5)), (2, dict(resume=True)),
-                                      (2, dict(_force_balance=True))])
+                                      (2, dict(_force_balance=True)), (2, dict(dQ="QEQ")), (3, dict(dQ="QUAD")),
+                                      (2, dict(dQ="QUAD", _force_balance=True))])
 def test_row_split_matches_single_process(world, kw):
     """Tensors split by rows over all ranks: the ranks agree BITWISE with each other; tensors that are not split equal the
     single-process result bitwise; the split ones to fp32 rounding (their dense factor's mode Gram is the sum of the ranks' partial

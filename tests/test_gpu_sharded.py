@@ -117,14 +117,17 @@ def _row_worker(rank, world, port, outdir, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(preconditioner_dtype=torch.float32), dict(preconditioner_dtype=torch.bfloat16, whiten_grad=True, shard_chunks=1),
-                                dict(preconditioner_dtype=torch.float32, update_preconditioner_first=False, _force_balance=True)])
+                                dict(preconditioner_dtype=torch.float32, update_preconditioner_first=False, _force_balance=True),
+                                dict(preconditioner_dtype=torch.float32, dQ="QEQ"), dict(preconditioner_dtype=torch.bfloat16, dQ="QUAD"),
+                                dict(preconditioner_dtype=torch.float32, dQ="QUAD", _force_balance=True)])
 def test_row_split_hip_engine_two_ranks_one_gpu(kw):
     """Row-split tensors on the REAL engine (include/psgdk.h "row shards"): two ranks on cuda:0 over gloo, two matrices split by rows --
     phased update around the exchange of the partial mode Grams, the diagonal factor's maximum over both blocks, two-phase balancing
     (third case: every gate fires), the RMS clip from both blocks' sums of h^2.  The ranks agree bitwise on every parameter; against
     the replicated single-process optimizer: unsplit tensors as in the test above, the split ones within the same bounds (their mode
     Gram is summed in another order: fp32 partials of the two blocks instead of one K loop); the replicated dense factor is the same on
-    both ranks up to the order of the norm bounds' fp32 atomics."""
+    both ranks up to the order of the norm bounds' fp32 atomics.  (Round 6: also the QEQ and QUAD geometries, whose phased update is the
+    same up to the dense factor's own step.)"""
     here = os.path.dirname(os.path.abspath(__file__))
     if here not in sys.path:
         sys.path.insert(0, here)
