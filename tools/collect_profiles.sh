@@ -40,6 +40,12 @@ python $R/tools/rocpd_stats.py $dbe > $out/gpt2-small-eq_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/p_lra -- python $R/bench.py --config vit-b-lra --steps 4 --warmup 1 > /dev/null 2> $out/rocprof_lra.err
 dbl=$(find /tmp/p_lra -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $dbl > $out/vit-b-lra_kernel_stats.md
+# (round 6) the bf16 leg of config 4 (SURVEY 8d quotes both dtypes) and an APPLY-ONLY step's dispatch sequence (update gated off: the steady state)
+python $R/bench.py --config vit-b-lra --bf16 --steps 30 --warmup 8 --no-cpu-baseline 2>> $out/bench.err | tail -1 > $out/bench_vit-b-lra_bf16.json
+rocprofv3 --kernel-trace --stats -d /tmp/p_lrab -- python $R/bench.py --config vit-b-lra --bf16 --steps 4 --warmup 1 > /dev/null 2> $out/rocprof_lra_bf16.err
+python $R/tools/rocpd_stats.py $(find /tmp/p_lrab -name "*.db" | head -1) > $out/vit-b-lra_bf16_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d /tmp/p_ao -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-peaks --no-secondary --no-roofline > /dev/null 2> $out/rocprof_apply_only.err
+python $R/tools/rocpd_sequence.py $(find /tmp/p_ao -name "*.db" | head -1) accumulate_kernel -3 > $out/apply_only_step_sequence.md
 # LeNet5 dispatch sequence (config 2) and the HBM counters of the LRA passes (config 4)
 rocprofv3 --kernel-trace --stats -d /tmp/p_l5 -- python $R/bench.py --config lenet5 --steps 12 --warmup 4 --no-cpu-baseline --no-apply-only --no-peaks > /dev/null 2> $out/rocprof_l5.err
 python $R/tools/rocpd_sequence.py $(find /tmp/p_l5 -name "*.db" | head -1) accumulate_kernel -3 > $out/lenet5_step_sequence.md
