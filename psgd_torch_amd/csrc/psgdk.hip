@@ -503,7 +503,7 @@ int psgdk_plan_set_stream_ids(psgdk_plan* plan, const uint32_t* ids) {
 int psgdk_plan_set_geometry(psgdk_plan* plan, int geometry) {
     if (!plan || geometry < PSGDK_GEOM_Q0P5EQ1P5 || geometry > PSGDK_GEOM_PRO4P) return PSGDK_ERR_INVALID;
     if (plan->state) return PSGDK_ERR_STATE;
-    if (!plan->shards.empty() && geometry != PSGDK_GEOM_Q0P5EQ1P5) return PSGDK_ERR_UNSUPPORTED;
+    if (!plan->shards.empty() && geometry != PSGDK_GEOM_Q0P5EQ1P5 && geometry != PSGDK_GEOM_QEQ && geometry != PSGDK_GEOM_QUAD) return PSGDK_ERR_UNSUPPORTED;
     plan->geometry = geometry;
     layout_arenas(plan);
     return PSGDK_OK;

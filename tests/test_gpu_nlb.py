@@ -177,3 +177,30 @@ def test_small_plans_are_bitwise_reproducible_and_plan_independent(pd):
                         bad.append(f"trial {trial}: tensor {i} {shapes[i]}, state item {k}: {what} differs by "
                                    f"{float((a.float() - b.float()).abs().max()):.3e}")
     assert not bad, "\n".join(bad[:40])
+
+
+def test_narrow_and_wide_members_agree_with_the_multi_launch_route(monkeypatch):
+    """Round 6: a plan with few wide factors runs the cooperative bound with members of 128 columns (six per 768-wide factor);
+    PSGDK_NLB_NARROW=0 (read at bind) keeps members of 256.  Both against the multi-launch route on the same inputs and draws, with the
+    soak test's bounds (what may differ: the order of the fp32 row-sum atomics)."""
+    dt, ulp = torch.bfloat16, 2.0 ** -7
+    for env, cols in (("0", 256), (None, 128)):
+        if env is None:
+            monkeypatch.delenv("PSGDK_NLB_NARROW", raising=False)
+        else:
+            monkeypatch.setenv("PSGDK_NLB_NARROW", env)
+        eng, _ = _engine(12, 768, dt)
+        info = eng.info()
+        assert info["nlb_coop"] == 1 and info["nlb_member_cols"] == cols, info
+        F, dp = info["dense_factors"], info["max_dense_dim"]
+        vsq_ref = torch.zeros(F, 4, 32, device=DEV)
+        v_ref = torch.zeros(F, 2, 32, dp, device=DEV, dtype=dt)
+        vsq, v = torch.zeros_like(vsq_ref), torch.zeros_like(v_ref)
+        for chain in (0, 1):
+            for it in range(20):
+                _run_bound(eng, chain, 0, 7000 + it, vsq_ref, v_ref)
+                _run_bound(eng, chain, 1, 7000 + it, vsq, v)
+                rowmax = v_ref.float().abs().amax(dim=-1, keepdim=True)
+                assert float(((v.float() - v_ref.float()).abs() / rowmax.clamp_min(1e-30)).amax()) <= 2 * ulp
+                assert float(((vsq - vsq_ref).abs() / vsq_ref.abs().clamp_min(1e-30)).amax()) <= 1e-2
+        assert eng.info()["nlb_fallbacks"] == 0
