@@ -72,6 +72,7 @@ struct psgdk_plan {
     int max_dp = 0;
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
     bool nlb_small = false;           // ... in its instantiation for plans whose widest factor is <= 128 (one workgroup per factor, 16 columns per wave)
+    bool nlb_k32 = false;             // ... factors of 25 .. 32 K steps (bf16 d <= 1024, fp32 d <= 512): members of 128 columns with 32 K steps of registers
     bool nlb_narrow = false;          // ... with 128 columns of A per member instead of 256 (round 6): plans with few wide factors -- a rank's share
                                       //     of a sharded job, a model of a few layers -- whose 2 x as many members still fit the CUs
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
@@ -1080,7 +1081,11 @@ static int nlb_plan_coop(psgdk_plan* P) {
     P->nlb_coop = false;
     if (P->dn.empty()) return PSGDK_OK;
     const int kstep = P->dtype == PSGDK_BF16 ? 32 : 16;
-    if (P->max_dp / kstep > 24) return PSGDK_OK;
+    // K steps of registers a member holds: 24 (768 bf16 / 384 fp32) with 256 or 128 columns per member, 32 (1024 / 512: GPT-2-medium's factors)
+    // with 128 columns only -- 256 columns x 32 K steps would be the whole register file
+    const int ksteps = P->max_dp / kstep;
+    if (ksteps > 32) return PSGDK_OK;
+    P->nlb_k32 = ksteps > 24;
     // members of a factor are dealt to one XCD (workgroup b is observed to run on XCD b % 8; speed only -- their slabs of A
     // then share an L2 -- the exchange protocol does not depend on it): per-XCD lists, longest-first packing
     std::vector<std::vector<NlbJob>> xcd(8);
@@ -1103,7 +1108,8 @@ static int nlb_plan_coop(psgdk_plan* P) {
     // PSGDK_NLB_NARROW=0 keeps the wide members (the GPU suite compares the two on one plan).
     const char* env_narrow = getenv("PSGDK_NLB_NARROW");
     for (int cols_per_wg : {128, 256}) {
-        if (cols_per_wg == 128 && !P->nlb_small && env_narrow && env_narrow[0] == '0') continue;
+        if (cols_per_wg == 128 && !P->nlb_small && !P->nlb_k32 && env_narrow && env_narrow[0] == '0') continue;
+        if (cols_per_wg == 256 && P->nlb_k32) break;
         for (auto& l : xcd) l.clear();
         for (int f : order) {
             const int S = (P->dn[f].dp + cols_per_wg - 1) / cols_per_wg;
@@ -1147,7 +1153,8 @@ static int nlb_plan_coop(psgdk_plan* P) {
                           (const void*)nlb_coop_kernel<bf16_t, 2, 24, true>, (const void*)nlb_coop_kernel<float, 2, 24, true>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 4, true>, (const void*)nlb_coop_kernel<float, 1, 8, true>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 24>, (const void*)nlb_coop_kernel<float, 1, 24>,
-                          (const void*)nlb_coop_kernel<bf16_t, 1, 24, true>, (const void*)nlb_coop_kernel<float, 1, 24, true>})
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 24, true>, (const void*)nlb_coop_kernel<float, 1, 24, true>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 32>, (const void*)nlb_coop_kernel<float, 1, 32>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
@@ -1157,10 +1164,12 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
     const unsigned F = (unsigned)P->dn.size();
     if (route < 0 ? P->nlb_coop : (route == 1)) {
         const bool bf = P->dtype == PSGDK_BF16;
+        if (stamps && P->nlb_k32) return PSGDK_ERR_UNSUPPORTED;      // (no instrumented instantiation of the 32-K-step variant)
         const void* k = stamps ? (P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4, true> : (const void*)nlb_coop_kernel<float, 1, 8, true>)
                                   : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24, true> : (const void*)nlb_coop_kernel<float, 1, 24, true>)
                                                   : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>))
                       : P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
+                      : P->nlb_k32 ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 32> : (const void*)nlb_coop_kernel<float, 1, 32>)
                       : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24> : (const void*)nlb_coop_kernel<float, 1, 24>)
                                       : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
         const DenseDesc* dn = P->d_dn; const NlbJob* jobs = P->d_nlb_jobs; unsigned* err = P->d_err;

@@ -44,7 +44,8 @@ def _run_bound(eng, chain, route, seed, vsq, v, fault=0):
 
 
 @pytest.mark.parametrize("dt,width,n_factors,iters", [(torch.bfloat16, 768, 62, 1000), (torch.float32, 384, 40, 300),
-                                                       (torch.bfloat16, 320, 24, 300), (torch.bfloat16, 768, 16, 300)])
+                                                       (torch.bfloat16, 320, 24, 300), (torch.bfloat16, 768, 16, 300),
+                                                       (torch.bfloat16, 1024, 16, 200), (torch.float32, 512, 12, 100)])
 def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
     """GPT-2-small's plan (62 factors x 768, S = 3) and two other widths: 2 chains x iters bounds with fresh noise each, a
     saturating side stream (siblings start at different times), consumers L1-warm by construction (the two exchange buffers
@@ -61,7 +62,8 @@ def test_cooperative_bound_soak_under_load(dt, width, n_factors, iters):
     info = eng.info()
     assert info["nlb_coop"] == 1, info
     # (round 6) plans whose members of 128 columns fit the CUs take them: 62 x 768 needs 372 workgroups and keeps members of 256 (S = 3),
-    # 16 x 768 runs six members per factor, 40 x 384 fp32 and 24 x 320 three
+    # 16 x 768 runs six members per factor, 40 x 384 fp32 and 24 x 320 three; 16 x 1024 bf16 (GPT-2-medium's width: a rank's share of an 8-way
+    # sharded job) and 12 x 512 fp32 run eight / four members with 32 K steps of registers -- widths the cooperative launch did not cover before
     assert info["nlb_member_cols"] == (256 if n_factors == 62 else 128), info
     F, dp = info["dense_factors"], info["max_dense_dim"]
     vsq_ref = torch.zeros(F, 4, 32, device=DEV)
