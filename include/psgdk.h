@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 402    /* round 6 (402): psgdk_precond_grad_apply (the parameter update fused into the apply's last product);
+#define PSGDK_VERSION 403    /* round 6 (403): psgdk_flat_set_clip_groups / psgdk_flat_apply_groups, psgdk_export_precond_grad clip = 2 (deferred clip of row shards),
+                                row shards for the QEQ / QUAD geometries, PSGDK_INFO_NLB_MEMBER_COLS;
+                                round 6 (402): psgdk_precond_grad_apply (the parameter update fused into the apply's last product);
                                 round 5 (401): row shards of the LRA preconditioner (psgdk_lra_set_row_shard, psgdk_lra_update_phase / _apply_phase / _phase_segments);
                                 round 4 (400): row shards (psgdk_plan_set_row_shard, psgdk_update_precond_begin / _finish, psgdk_balance_phase),
                                 psgdk_profile_read_calls; (300: test hooks moved to psgdk_test.h; 200: PSGDK_MAX_DIMS 8 -> 26, PSGDK_ERR_NLB_TIMEOUT) */
@@ -208,7 +210,8 @@ int psgdk_precond_grad_apply(psgdk_plan* plan, int source, void* const* params, 
 
 /* Sharded path (build-side design): the clipped preconditioned gradients (wrapped_as_torch_optimizer_for_ddp.py:153-156)
  * of ALL tensors of the plan, exported in one launch to caller buffers outs[t] (logical contiguous order, element type
- * out_dtype) -- normally this rank's slices of the flat all-gather buffer. */
+ * out_dtype) -- normally this rank's slices of the flat all-gather buffer.  clip: 0 = as they are, 1 = clipped, 2 (round 6) = clipped except
+ * ROW SHARDS, which leave unclipped for psgdk_flat_apply_groups (below) to clip after the exchange. */
 int psgdk_export_precond_grad(psgdk_plan* plan, void* const* outs, int out_dtype, int clip, float max_avg_amp, float max_elem_amp,
                               void* stream);
 /* copy h of tensor t to `out` (logical layout, contiguous, out_dtype) -- the return value of precond_grad_kron.
@@ -225,6 +228,18 @@ int psgdk_flat_create(psgdk_flat** out, int n, const int64_t* numel, const int64
 int psgdk_flat_destroy(psgdk_flat* flat);
 int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
                      float decoupled_wd, void* stream);
+/* Deferred clip of ROW SHARDS (round 6, version 403): the RMS clip of a row-split tensor (..._ddp.py:153-155) needs the sum of h^2 over ALL its
+ * row blocks.  Instead of a collective of its own between psgdk_precond_grad and the export, every member exports its block UNCLIPPED
+ * (psgdk_export_precond_grad with clip = 2) and puts its partial sum -- the fp32 word at PSGDK_INFO_HSUMSQ_OFFSET + 4 t -- into its segment of
+ * the exchange buffer; after the gather psgdk_flat_apply_groups clips the blocks where it applies them.  psgdk_flat_set_clip_groups declares
+ * which pieces of the flat layout belong to which row-split tensor (piece_group[t] = group, or -1: applied as it is), where member 0's partial
+ * sum of each group lies inside h_flat (sum_off_bytes[g], a multiple of 4) and how far apart the members' words are (member_stride_bytes: the
+ * segment size); the sums are added in member order (the same bits on every rank), numel_clip[g] is the WHOLE tensor's element count.  Same
+ * arithmetic as the owner-side clip: scale = max_avg_amp / rms when rms > max_avg_amp, rounded to h_dtype, clamped to +-max_elem_amp. */
+int psgdk_flat_set_clip_groups(psgdk_flat* flat, int n_groups, const int32_t* piece_group, const int64_t* sum_off_bytes,
+                               int64_t member_stride_bytes, int members, const int64_t* numel_clip);
+int psgdk_flat_apply_groups(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                            float decoupled_wd, float max_avg_amp, float max_elem_amp, void* stream);
 /* LRAWhiten.step's vector work around the preconditioner (psgd.py:1142-1155, 1179-1187), one launch each over ALL parameters of
  * the flat layout (h_offset[t] = running sum of numel: the concatenation order of psgd.py:1142):
  * psgdk_flat_gather: g_flat[off_t + i] = grads[t][i] (cast to flat_dtype); if m_flat: m <- beta m + (1 - beta) g in place

@@ -13,7 +13,7 @@ BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 402      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 403      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -104,6 +104,9 @@ SIGNATURES = {
     "psgdk_flat_destroy": (C.c_int, [C.c_void_p]),
     "psgdk_flat_apply": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                    C.c_void_p]),
+    "psgdk_flat_set_clip_groups": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "psgdk_flat_apply_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_void_p]),
     "psgdk_flat_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                     C.c_void_p]),
     "psgdk_flat_apply_clipped": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,

@@ -1819,7 +1819,12 @@ struct psgdk_flat {
     FlatDesc* d_fd = nullptr; FlatChunk* d_chunks = nullptr; unsigned n_chunks = 0;
     void** d_ptrs = nullptr;
     std::vector<const void*> h_ptrs;
-    ~psgdk_flat() { if (d_fd) (void)hipFree(d_fd); if (d_chunks) (void)hipFree(d_chunks); if (d_ptrs) (void)hipFree(d_ptrs); }
+    // psgdk_flat_set_clip_groups: piece -> clip group (-1: none), the groups, where the members' partial sums lie inside the gathered buffer
+    int* d_piece_group = nullptr; FlatGroup* d_groups = nullptr; int n_groups = 0, members = 0; long long member_stride = 0;
+    ~psgdk_flat() {
+        if (d_fd) (void)hipFree(d_fd); if (d_chunks) (void)hipFree(d_chunks); if (d_ptrs) (void)hipFree(d_ptrs);
+        if (d_piece_group) (void)hipFree(d_piece_group); if (d_groups) (void)hipFree(d_groups);
+    }
 };
 
 int psgdk_flat_create(psgdk_flat** out, int n, const int64_t* numel, const int64_t* h_offset) {
@@ -1853,6 +1858,43 @@ int psgdk_flat_apply(psgdk_flat* flat, void* const* params, int param_dtype, con
     if (flat->n_chunks)
         hipLaunchKernelGGL(flat_apply_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks, (void* const*)flat->d_ptrs,
                            param_dtype, h_flat, h_dtype, lr, 1.0f - decoupled_wd * lr, (const float*)nullptr, 1.f, 0.f, 0.f);
+    HIPCHK(hipGetLastError());
+    return PSGDK_OK;
+}
+
+int psgdk_flat_set_clip_groups(psgdk_flat* flat, int n_groups, const int32_t* piece_group, const int64_t* sum_off_bytes,
+                               int64_t member_stride_bytes, int members, const int64_t* numel_clip) {
+    if (!flat || n_groups < 0) return PSGDK_ERR_INVALID;
+    if (flat->d_piece_group) { (void)hipFree(flat->d_piece_group); flat->d_piece_group = nullptr; }
+    if (flat->d_groups) { (void)hipFree(flat->d_groups); flat->d_groups = nullptr; }
+    flat->n_groups = 0;
+    if (n_groups == 0) return PSGDK_OK;
+    if (!piece_group || !sum_off_bytes || !numel_clip || members < 1 || member_stride_bytes < 0 || (member_stride_bytes & 3)) return PSGDK_ERR_INVALID;
+    std::vector<int> pg(piece_group, piece_group + flat->n);
+    std::vector<FlatGroup> gs(n_groups);
+    for (int t = 0; t < flat->n; ++t) if (pg[t] < -1 || pg[t] >= n_groups) return PSGDK_ERR_INVALID;
+    for (int g = 0; g < n_groups; ++g) {
+        if (sum_off_bytes[g] < 0 || (sum_off_bytes[g] & 3) || numel_clip[g] <= 0) return PSGDK_ERR_INVALID;
+        gs[g] = FlatGroup{(long long)sum_off_bytes[g], (long long)numel_clip[g]};
+    }
+    int rc;
+    if ((rc = upload(&flat->d_piece_group, pg)) || (rc = upload(&flat->d_groups, gs))) return rc;
+    flat->n_groups = n_groups; flat->members = members; flat->member_stride = member_stride_bytes;
+    return PSGDK_OK;
+}
+
+int psgdk_flat_apply_groups(psgdk_flat* flat, void* const* params, int param_dtype, const void* h_flat, int h_dtype, float lr,
+                            float decoupled_wd, float max_avg_amp, float max_elem_amp, void* stream) {
+    if (!flat || !params || !h_flat || (param_dtype != PSGDK_BF16 && param_dtype != PSGDK_F32) || (h_dtype != PSGDK_BF16 && h_dtype != PSGDK_F32) ||
+        !(lr > 0.f) || !(decoupled_wd >= 0.f) || !(max_elem_amp >= max_avg_amp) || !(max_avg_amp > 0.f)) return PSGDK_ERR_INVALID;
+    if (!flat->n_groups) return PSGDK_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = upload_ptrs(flat->d_ptrs, flat->h_ptrs, (const void* const*)params, flat->n, st))) return rc;
+    if (flat->n_chunks)
+        hipLaunchKernelGGL(flat_apply_kernel, dim3(flat->n_chunks), dim3(256), 0, st, flat->d_fd, flat->d_chunks, (void* const*)flat->d_ptrs,
+                           param_dtype, h_flat, h_dtype, lr, 1.0f - decoupled_wd * lr, (const float*)nullptr, 1.f, max_avg_amp, max_elem_amp,
+                           (const int*)flat->d_piece_group, (const FlatGroup*)flat->d_groups, flat->member_stride, flat->members);
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }

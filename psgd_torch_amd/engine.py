@@ -98,7 +98,19 @@ class FlatApply:
         except Exception:
             pass
 
-    def apply(self, params: Sequence[torch.Tensor], flat: torch.Tensor, lr: float, decoupled_wd: float):
+    def set_clip_groups(self, piece_group: Sequence[int], sum_off_bytes: Sequence[int], member_stride_bytes: int, members: int,
+                        numel_clip: Sequence[int]):
+        """Row-split tensors whose RMS clip is deferred to apply() (psgdk_flat_set_clip_groups): piece_group[t] = the group of piece t or -1;
+        member m's fp32 partial sum of h^2 of group g lies at byte sum_off_bytes[g] + m * member_stride_bytes of the gathered buffer."""
+        n_groups = len(sum_off_bytes)
+        pg = (C.c_int32 * self.n)(*[int(x) for x in piece_group])
+        so = (C.c_int64 * max(n_groups, 1))(*[int(x) for x in sum_off_bytes])
+        nc = (C.c_int64 * max(n_groups, 1))(*[int(x) for x in numel_clip])
+        L.check(self.lib.psgdk_flat_set_clip_groups(self._h, n_groups, pg, so, int(member_stride_bytes), int(members), nc), "flat_set_clip_groups")
+        self.n_groups = n_groups
+
+    def apply(self, params: Sequence[torch.Tensor], flat: torch.Tensor, lr: float, decoupled_wd: float, clip=None):
+        """clip = (max_avg_amp, max_elem_amp): also clip the pieces of the declared groups (set_clip_groups) from the sums inside `flat`."""
         live = [(p, n) for p, n in zip(params, self.numels) if p is not None]      # None: skipped this step
         _check_tensors("params", [p for p, _ in live], [n for _, n in live], self.device)
         if len(params) != self.n:
@@ -110,6 +122,10 @@ class FlatApply:
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if not live:
+            return
+        if clip is not None and getattr(self, "n_groups", 0):
+            L.check(self.lib.psgdk_flat_apply_groups(self._h, pa, L.dtype_code(live[0][0].dtype), flat.data_ptr(), L.dtype_code(flat.dtype),
+                                                     float(lr), float(decoupled_wd), float(clip[0]), float(clip[1]), st), "flat_apply_groups")
             return
         L.check(self.lib.psgdk_flat_apply(self._h, pa, L.dtype_code(live[0][0].dtype), flat.data_ptr(), L.dtype_code(flat.dtype),
                                           float(lr), float(decoupled_wd), st), "flat_apply")
@@ -420,9 +436,9 @@ class KronEngine:
         return out
 
     @_on_device
-    def export_precond_grad(self, outs: Sequence[torch.Tensor], clip: bool = True, max_avg_amp: float = 2.0, max_elem_amp: float = 10.0):
+    def export_precond_grad(self, outs: Sequence[torch.Tensor], clip=True, max_avg_amp: float = 2.0, max_elem_amp: float = 10.0):
         """All tensors' (clipped) preconditioned gradients into caller buffers, ONE launch (the sharded path's export into the
-        rank's segment of the all-gather buffer)."""
+        rank's segment of the all-gather buffer).  clip = 2: row shards leave unclipped (FlatApply.apply(clip=...) clips them after the exchange)."""
         dt = _check_tensors("outs", outs, self.numels, self.device)
         oa = L.ptr_array(outs)
         self._keep_o = [oa, list(outs)]

@@ -447,7 +447,13 @@ class KWNS4(torch.optim.Optimizer):
                 return (r1 - r0) * shapes[i][1] if r0 is not None else (math.prod(shapes[i]) if len(shapes[i]) else 1)
             numels = [pnumel(pc) for pc in pieces]
             pad8 = [(n + 7) // 8 * 8 for n in numels]
-            per_rank = [sum(pad8[k] for k, pc in enumerate(pieces) if pc[3] == r) for r in range(self.world)]
+            # (round 6) the RMS clip of a row-split tensor is DEFERRED to the flat apply: every rank's segment starts with one slot of 8 elements
+            # per row-split tensor of this bucket, holding the fp32 sum of h^2 of the rank's own block -- it travels with the h exchange instead
+            # of in an all-reduce of its own between precond_grad and the export (engines without the deferred form keep that all-reduce)
+            split_ids = sorted(b.blocks)
+            b.defer_clip = bool(split_ids) and hasattr(self._engine_factory.FlatApply, "set_clip_groups")
+            head = 8 * len(split_ids) if b.defer_clip else 0
+            per_rank = [head + sum(pad8[k] for k, pc in enumerate(pieces) if pc[3] == r) for r in range(self.world)]
             seg = max(per_rank + [8])
             b.seg = seg
             # what each rank really has to send (elements at the head of its segment).  A dominant tensor (GPT-2's wte: 38.6 M of the
@@ -456,7 +462,7 @@ class KWNS4(torch.optim.Optimizer):
             b.used = per_rank
             b.uneven = seg * self.world > 1.25 * sum(per_rank)
             b.flat = torch.zeros(self.world * seg, dtype=pd, device=p0.device)
-            offs = [r * seg for r in range(self.world)]
+            offs = [r * seg + head for r in range(self.world)]
             b.h_views, h_offsets = [None] * len(shapes), []
             for k, (i, r0, r1, r) in enumerate(pieces):
                 view = b.flat[offs[r]:offs[r] + numels[k]].view(shapes[i] if r0 is None else (r1 - r0, shapes[i][1]))
@@ -467,6 +473,15 @@ class KWNS4(torch.optim.Optimizer):
             b.pieces = pieces
             # p <- p (1 - wd lr) - lr h for all pieces from the gathered buffer: one launch (engine-provided)
             b.flat_apply = self._engine_factory.FlatApply(numels, h_offsets, p0.device)
+            if b.defer_clip:
+                esz = b.flat.element_size()
+                group_of = {i: g for g, i in enumerate(split_ids)}
+                b.flat_apply.set_clip_groups([group_of.get(pc[0], -1) if pc[1] is not None else -1 for pc in pieces],
+                                             [8 * g * esz for g in range(len(split_ids))], seg * esz, self.world,
+                                             [shapes[i][0] * shapes[i][1] for i in split_ids])
+                # where this rank's engine puts its own partial sums: slot g of its segment, read as one fp32 word
+                own = b.flat[self.rank * seg:self.rank * seg + head].view(torch.uint8)
+                b.sum_slots = {i: own[8 * g * esz:8 * g * esz + 4].view(torch.float32) for g, i in enumerate(split_ids)}
         self._buckets[key] = b
         pending = getattr(self, "_pending_restore", None)
         if pending and self._key_str(key) in pending:      # load_state_dict() was called before this bucket existed
@@ -588,8 +603,13 @@ class KWNS4(torch.optim.Optimizer):
                 _unpack(back)
             else:
                 eng.precond_grad(src_p)
-            if shard_k:
-                # the RMS clip of a row-split tensor averages over ALL its rows (..._ddp.py:153-155): the blocks' sums of h^2 are summed
+            defer = bool(shard_k) and getattr(b, "defer_clip", False)
+            if shard_k and defer:
+                # the RMS clip of a row-split tensor averages over ALL its rows (..._ddp.py:153-155): this rank's sums of h^2 go into its segment
+                # of the exchange buffer and the flat apply clips the blocks after the gather -- no collective of its own
+                for k in shard_k:
+                    b.sum_slots[b.owned[k]].copy_(eng.hsumsq[k:k + 1])
+            elif shard_k:
                 self._reduce_sum(eng.hsumsq, shard_k)
             if fused:
                 pass
@@ -598,7 +618,8 @@ class KWNS4(torch.optim.Optimizer):
                 _unpack(back)
             else:
                 # all owned tensors' clipped h straight into this rank's segment of the exchange buffer: one launch
-                eng.export_precond_grad([b.h_views[i] for i in b.owned], clip=True, max_avg_amp=max_avg_amp, max_elem_amp=max_element_amp)
+                eng.export_precond_grad([b.h_views[i] for i in b.owned], clip=2 if defer else True, max_avg_amp=max_avg_amp,
+                                        max_elem_amp=max_element_amp)
         elif updateP_first or updateP_last:
             self._uniforms(len(plist))                    # keep the gate stream in lock-step with the owning ranks
         work = None
@@ -712,7 +733,10 @@ class KWNS4(torch.optim.Optimizer):
             whole, back = _packed([self._data_of(p) if id(p) in present else None for p in b.params])
             # one entry per piece of the exchange: the tensor, or its row block (contiguous rows of the packed tensor)
             lps = [None if whole[i] is None else (whole[i] if r0 is None else whole[i][r0:r1]) for i, r0, r1, _ in b.pieces]
-            b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
+            if getattr(b, "defer_clip", False):
+                b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0, clip=tuple(group["grad_clip_max_amps"]))
+            else:
+                b.flat_apply.apply(lps, b.flat, lr, wd if (wd > 0.0 and decoupled) else 0.0)     # ..._ddp.py:120,157
             _unpack(back)
         b.step += 1
         for p in plist:

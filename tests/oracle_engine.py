@@ -19,13 +19,30 @@ class _TorchFlatApply:
     def __init__(self, numels, offsets, device):
         self.numels, self.offsets = list(numels), list(offsets)
 
-    def apply(self, params, flat, lr, decoupled_wd):
-        for p, n, o in zip(params, self.numels, self.offsets):
+    def set_clip_groups(self, piece_group, sum_off_bytes, member_stride_bytes, members, numel_clip):
+        self.groups = (list(piece_group), list(sum_off_bytes), int(member_stride_bytes), int(members), list(numel_clip))
+        self.n_groups = len(sum_off_bytes)
+
+    def apply(self, params, flat, lr, decoupled_wd, clip=None):
+        raw = flat.view(torch.uint8)
+        for t, (p, n, o) in enumerate(zip(params, self.numels, self.offsets)):
             if p is None:
                 continue
+            h = flat[o:o + n]
+            if clip is not None and getattr(self, "n_groups", 0) and self.groups[0][t] >= 0:
+                # a row-split tensor's piece: the members' partial sums of h^2 from inside the gathered buffer, in member order
+                pg, so, stride, members, nc = self.groups
+                g = pg[t]
+                tot = torch.zeros((), dtype=torch.float32)
+                for m in range(members):
+                    tot = tot + raw[so[g] + m * stride:so[g] + m * stride + 4].view(torch.float32)[0]
+                avg = torch.sqrt(tot / nc[g]).to(h.dtype)
+                if avg > clip[0]:
+                    h = h * (clip[0] / avg)
+                h = h.clamp(min=-clip[1], max=clip[1])
             if decoupled_wd:
                 p.mul_(1.0 - decoupled_wd * lr)
-            p.subtract_(flat[o:o + n].view_as(p).to(p.dtype), alpha=lr)
+            p.subtract_(h.view_as(p).to(p.dtype), alpha=lr)
 
 
 class OracleEngine:
@@ -221,6 +238,8 @@ class OracleEngine:
             p.subtract_(self._clipped(k, max_avg_amp, max_elem_amp).view_as(p).to(p.dtype), alpha=lr)
 
     def read_precond_grad(self, k, out=None, clip=False, max_avg_amp=2.0, max_elem_amp=10.0):
+        if clip == 2 and k in self.row_shards:      # deferred: the flat apply clips this block after the exchange
+            clip = False
         h = self._clipped(k, max_avg_amp, max_elem_amp) if clip else self.h[k]
         if out is None:
             return h.clone()

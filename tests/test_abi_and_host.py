@@ -63,7 +63,7 @@ def test_row_shard_declaration_is_validated(lib):
     from psgd_torch_amd import _lib
     """psgdk_plan_set_row_shard (host-only part of the row-shard ABI): a row block must be a matrix with a diagonal dim-0 factor and a
     dense dim-1 factor -- for the block's own shape AND for the whole matrix --, inside the whole matrix, declared once, with one
-    (member, members) per plan, in the default geometry; the exchange record holds the fp32 partial Gram + a scalar slot per shard."""
+    (member, members) per plan, in the Q0.5EQ1.5 / QEQ / QUAD geometries; the exchange record holds the fp32 partial Gram + a scalar slot per shard."""
     shapes = [(128, 32), (32, 32), (64,), (256, 32)]
     rc, plan = _plan(lib, shapes)
     assert rc == 0
@@ -85,7 +85,14 @@ def test_row_shard_declaration_is_validated(lib):
     assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_EQ) == _lib.PSGDK_ERR_UNSUPPORTED
     lib.psgdk_plan_destroy(plan)
     rc, plan = _plan(lib, shapes)
+    # (round 6) QEQ and QUAD share the default geometry's phased update: they take row shards; the others do not, in either order of the calls
     assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_QEQ) == 0
+    assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 128, 1, 4) == 0
+    assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_QUAD) == 0
+    assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_QEP) == _lib.PSGDK_ERR_UNSUPPORTED
+    lib.psgdk_plan_destroy(plan)
+    rc, plan = _plan(lib, shapes)
+    assert lib.psgdk_plan_set_geometry(plan, _lib.GEOM_QEP) == 0
     assert lib.psgdk_plan_set_row_shard(plan, 0, 512, 128, 1, 4) == _lib.PSGDK_ERR_UNSUPPORTED
     lib.psgdk_plan_destroy(plan)
 

@@ -174,6 +174,15 @@ def _row_worker(rank, world, port, outdir, kw, shapes, steps):
                 o._update_draws = lambda b, plist: dict(noise=None, balance_mask=[True] * len(b.owned))
             return o
         opt = make()
+        # (round 6) the sums of h^2 of a row-split tensor's blocks ride inside the h exchange (deferred clip): the only all-reduce a step may
+        # still issue is the balancing maximum, on the 1 % of steps whose gate fires
+        n_allreduce = [0]
+        real_all_reduce = torch.distributed.all_reduce
+
+        def counting_all_reduce(*a, **k):
+            n_allreduce[0] += 1
+            return real_all_reduce(*a, **k)
+        torch.distributed.all_reduce = counting_all_reduce
         g = torch.Generator().manual_seed(99)
         for t in range(steps):
             if resume and t == 2:
@@ -183,6 +192,8 @@ def _row_worker(rank, world, port, outdir, kw, shapes, steps):
             for p in params:
                 p.grad = 0.3 * torch.randn(p.shape, generator=g)
             opt.step()
+        torch.distributed.all_reduce = real_all_reduce
+        assert force or n_allreduce[0] == 0, n_allreduce[0]
         split = sorted(i for b in opt._buckets.values() for i, p in enumerate(params) if any(p is b.params[j] for j in b.blocks))
         load = sum(len(b.owned) for b in opt._buckets.values())
         torch.save({"params": [p.data.clone() for p in params], "split": split, "load": load}, os.path.join(outdir, f"r{rank}.pt"))
