@@ -422,7 +422,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    MODES = {"sharded": dict(shard_state=True),                         # 2 chunks: the first chunk's all-gather under the second one's arithmetic
+    MODES = {"sharded": dict(shard_state=True, shard_chunks=2),         # 2 chunks: the first chunk's all-gather under the second one's arithmetic
+             # (named explicitly since round 6: an optimizer that names no count now takes 1 or 2 from the exchange model -- the probe below times both)
              "sharded, one exchange": dict(shard_state=True, shard_chunks=1),
              "sharded, four chunks": dict(shard_state=True, shard_chunks=4),
              "sharded, p2p": dict(shard_state=True, shard_exchange="p2p"),       # every chunk as 2 (N - 1) direct sends / receives
