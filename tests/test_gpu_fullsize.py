@@ -185,10 +185,15 @@ def test_gpt2_small_wte_bf16_splitk_gram(fused, monkeypatch):
     assert info["nlb_coop"] == fused, info
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("shape", [(4096, 1024), (1024, 1024), (1024, 4096)])
-def test_gpt2_medium_shapes_bf16(shape):
-    info, _ = _seam_case(shape, torch.bfloat16, None, seed=5)
-    assert info["nlb_coop"] == 0 and info["max_dense_dim"] == 1024, info      # too wide for the register slab: multi-launch route
+def test_gpt2_medium_shapes_bf16(shape, fused, monkeypatch):
+    """GPT-2-medium's 1024-wide factors on both norm-bound routes: the multi-launch one (what the whole 123-factor plan runs) and, since round 6,
+    the cooperative launch with 32 K steps of registers and members of 128 columns (plans of up to 31 such factors: a rank's share)."""
+    info, _ = _seam_case(shape, torch.bfloat16, fused, monkeypatch=monkeypatch, seed=5)
+    assert info["nlb_coop"] == fused and info["max_dense_dim"] == 1024, info
+    if fused:
+        assert info["nlb_member_cols"] == 128, info
 
 
 def test_gpt2_small_shape_fp32():
