@@ -295,7 +295,7 @@ int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr);
  * psgdk_lra_phase_segments names over the ranks -- op 0: sum, op 1: maximum -- and writes the result back on every rank (one collective
  * per phase: 4 per update, the fifth phase ends with nothing to exchange; 3 per apply, the last one being the sum of out^2 the RMS clip
  * reads through psgdk_lra_last_sumsq).  The Philox counters of the damping noise run over the WHOLE vector (row0 + local row), so the
- * shards draw what one GPU would.  Tuned rank classes only (r <= 64): PSGDK_ERR_UNSUPPORTED above; on a declared shard the one-call
+ * shards draw what one GPU would.  Every rank the engine holds (round 6: the general path above rank 64 is cut into the same phases); on a declared shard the one-call
  * forms return PSGDK_ERR_STATE.  psgd_torch_amd/lra_sharded.py drives this over torch.distributed. */
 #define PSGDK_LRA_UPDATE_PHASES 5
 #define PSGDK_LRA_APPLY_PHASES 3

@@ -2469,12 +2469,17 @@ static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* g
 }
 
 // ranks above 64: the general path (kernels_lra_gen.hiph), stage for stage the tuned one
+// phase: -1 = the whole update; 0 .. 4 = the phases of a row-sharded preconditioner (round 6: the general path cut where a reduction over
+// ALL rows is complete, like the tuned rank classes -- psgdk_lra_phase_segments names the words to reduce over the ranks in between):
+//   0: clear, Grams U^T U, V^T V   1: small1, rotation (+ V^T (d h), U^T (v / d)), Grams of the rotated factors   2: small2, pass 3
+//   3: small3, pass 4 (maxima)      4: small4, pass 5
 static int lra_update_general(psgdk_lra* L, const void* g, const void* v_noise, uint64_t seed, uint64_t offset, int update_u, float lr,
-                              float betaL, float damping, hipStream_t st) {
+                              float betaL, float damping, hipStream_t st, int phase = -1) {
     const int64_t N = L->N; const int r = L->r;
     const LragLayout Y = lrag_layout(r);
     float* sm = (float*)(L->work + L->sm_off);
-    HIPCHK(hipMemsetAsync(sm, 0, (size_t)(Y.SC + 7) * 4, st));       // everything but the sum of h^2 of the last apply
+    const auto on = [phase](int p) { return phase < 0 || phase == p; };
+    if (on(0)) HIPCHK(hipMemsetAsync(sm, 0, (size_t)(Y.SC + 7) * 4, st));       // everything but the sum of h^2 of the last apply
     const unsigned tiles = (unsigned)((r + 15) / 16);
     const unsigned slices = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4096 / ((int64_t)tiles * tiles) + 1, 1024), (N + 255) / 256));
     const unsigned gw = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + 3) / 4, 2048));
@@ -2483,39 +2488,51 @@ static int lra_update_general(psgdk_lra* L, const void* g, const void* v_noise, 
     LRAG_T({
         T* Qh = (T*)(L->work + L->qh_off); T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
-        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset};
-        hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU, sm + Y.VTV,
-                           (float*)nullptr, 3);
-        hipLaunchKernelGGL(lrag_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
-        if (shm_rot > 64u * 1024u)
-            HIPCHK(hipFuncSetAttribute((const void*)lrag_rotate_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rot));
-        hipLaunchKernelGGL(lrag_rotate_kernel<T>, dim3(gw), dim3(256), shm_rot, st, U, V, (const T*)d, vh, N, sm, Y);
-        hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU2, sm + Y.VTV2,
-                           sm + Y.VTU, 7);
-        hipLaunchKernelGGL(lrag_small2_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
-        hipLaunchKernelGGL(lrag_pass3_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, Qh, iq, N, sm, Y);
-        hipLaunchKernelGGL(lrag_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, Y);
-        hipLaunchKernelGGL(lrag_pass4_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, (const T*)Qh, (const T*)iq,
-                           diff, N, sm, Y);
-        hipLaunchKernelGGL(lrag_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, Y, update_u ? 1 : 0, lr, betaL);
-        hipLaunchKernelGGL(lrag_pass5_kernel<T>, dim3(gw), dim3(256), 0, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff, N,
-                           update_u ? 1 : 0, (const float*)sm, Y);
+        const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset, L->row0};
+        if (on(0))
+            hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU, sm + Y.VTV,
+                               (float*)nullptr, 3);
+        if (on(1)) {
+            hipLaunchKernelGGL(lrag_small1_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
+            if (shm_rot > 64u * 1024u)
+                HIPCHK(hipFuncSetAttribute((const void*)lrag_rotate_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rot));
+            hipLaunchKernelGGL(lrag_rotate_kernel<T>, dim3(gw), dim3(256), shm_rot, st, U, V, (const T*)d, vh, N, sm, Y);
+            hipLaunchKernelGGL(lrag_gram_kernel<T>, dim3(tiles, tiles, slices), dim3(256), 0, st, (const T*)U, (const T*)V, N, r, sm + Y.UTU2, sm + Y.VTV2,
+                               sm + Y.VTU, 7);
+        }
+        if (on(2)) {
+            hipLaunchKernelGGL(lrag_small2_kernel<T>, dim3(1), dim3(256), 0, st, sm, Y);
+            hipLaunchKernelGGL(lrag_pass3_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, Qh, iq, N, sm, Y);
+        }
+        if (on(3)) {
+            hipLaunchKernelGGL(lrag_small3_kernel<T>, dim3(1), dim3(64), 0, st, sm, Y);
+            hipLaunchKernelGGL(lrag_pass4_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)U, (const T*)V, (const T*)d, vh, (const T*)Qh, (const T*)iq,
+                               diff, N, sm, Y);
+        }
+        if (on(4)) {
+            hipLaunchKernelGGL(lrag_small4_kernel<T>, dim3(1), dim3(64), 0, st, sm, L->Luvd, Y, update_u ? 1 : 0, lr, betaL);
+            hipLaunchKernelGGL(lrag_pass5_kernel<T>, dim3(gw), dim3(256), 0, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff, N,
+                               update_u ? 1 : 0, (const float*)sm, Y);
+        }
     });
     HIPCHK(hipGetLastError());
     return PSGDK_OK;
 }
-static int lra_apply_general(psgdk_lra* L, const void* g, void* out, hipStream_t st) {
+static int lra_apply_general(psgdk_lra* L, const void* g, void* out, hipStream_t st, int phase = -1) {      // phase: -1 = all three stages, 0 .. 2 = one
     const int64_t N = L->N; const int r = L->r;
     const LragLayout Y = lrag_layout(r);
     float* sm = (float*)(L->work + L->sm_off);
-    HIPCHK(hipMemsetAsync(sm + Y.VTX2, 0, (size_t)(2 * r) * 4, st));
-    HIPCHK(hipMemsetAsync(sm + Y.SC + 7, 0, 4, st));
+    if (phase <= 0) {
+        HIPCHK(hipMemsetAsync(sm + Y.VTX2, 0, (size_t)(2 * r) * 4, st));
+        HIPCHK(hipMemsetAsync(sm + Y.SC + 7, 0, 4, st));
+    }
     const unsigned gw = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N + 3) / 4, 2048));
     LRAG_T({
         T* y = (T*)(L->work + L->y_off);
         for (int stage = 0; stage < 3; ++stage)
-            hipLaunchKernelGGL(lrag_apply_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)L->U, (const T*)L->V, (const T*)L->d, (const T*)g, y,
-                               (T*)out, N, stage, sm, Y);
+            if (phase < 0 || phase == stage)
+                hipLaunchKernelGGL(lrag_apply_kernel<T>, dim3(gw), dim3(256), 0, st, (const T*)L->U, (const T*)L->V, (const T*)L->d, (const T*)g, y,
+                                   (T*)out, N, stage, sm, Y);
     });
 #undef LRAG_T
     HIPCHK(hipGetLastError());
@@ -2652,8 +2669,7 @@ int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* strea
 // ---- row shards of one LRA preconditioner (last row) -----------------------------------------------------
 int psgdk_lra_set_row_shard(psgdk_lra* lra, int64_t row0) {
     if (!lra || row0 < 0) return PSGDK_ERR_INVALID;
-    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;       // (the general-rank path keeps r x r matrices in global memory: not split into phases)
-    lra->row0 = row0; lra->sharded = true;
+    lra->row0 = row0; lra->sharded = true;      // (every rank: the tuned classes and, since round 6, the general path are cut into the same phases)
     return PSGDK_OK;
 }
 
@@ -2662,14 +2678,15 @@ int psgdk_lra_update_phase(psgdk_lra* lra, int phase, const void* g, const void*
     const int rc = lra_update_args_ok(lra, g, lr, betaL, damping);
     if (rc) return rc;
     if (phase < 0 || phase >= PSGDK_LRA_UPDATE_PHASES) return PSGDK_ERR_INVALID;
-    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
+    if (lra->r > LRA_RMAX)
+        return lra_update_general(lra, g, v_noise, seed, offset, update_u, lr, betaL, damping, (hipStream_t)stream, phase);
     return lra_update_phase_t(lra, phase, g, v_noise, seed, offset, update_u, lr, betaL, damping, (hipStream_t)stream);
 }
 
 int psgdk_lra_apply_phase(psgdk_lra* lra, int phase, const void* g, void* out, void* stream) {
     if (!lra || !g || !out || phase < 0 || phase >= PSGDK_LRA_APPLY_PHASES) return PSGDK_ERR_INVALID;
     if (!lra->work) return PSGDK_ERR_STATE;
-    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
+    if (lra->r > LRA_RMAX) return lra_apply_general(lra, g, out, (hipStream_t)stream, phase);
     return lra_apply_phase_t(lra, phase, g, out, (hipStream_t)stream);
 }
 
@@ -2677,11 +2694,28 @@ int psgdk_lra_apply_phase(psgdk_lra* lra, int phase, const void* g, void* out, v
 // next phase reads: up to PSGDK_LRA_MAX_SEGMENTS runs of words, each summed (op 0) or maximised (op 1) over the shards
 int psgdk_lra_phase_segments(const psgdk_lra* lra, int kind, int phase, int* n_segments, int64_t* word_offset, int* words, int* op) {
     if (!lra || !n_segments || !word_offset || !words || !op) return PSGDK_ERR_INVALID;
-    if (lra->r > LRA_RMAX) return PSGDK_ERR_UNSUPPORTED;
     const int tpr = lra_tpr_of_rank(lra->r);
     const int64_t base = (int64_t)(lra->sm_off / 4);
     int n = 0;
     auto seg = [&](int off, int cnt, int o) { word_offset[n] = base + off; words[n] = cnt; op[n] = o; ++n; };
+    if (lra->r > LRA_RMAX) {      // the general path's scratch layout (kernels_lra_gen.hiph): r x r matrices and r-vectors without padding
+        const LragLayout Y = lrag_layout(lra->r);
+        const int r = lra->r;
+        if (kind == 0) {
+            if (phase == 0) seg(Y.UTU, 2 * Y.R2, 0);                                              // U^T U, V^T V
+            else if (phase == 1) { seg(Y.VTU, Y.R2, 0); seg(Y.UTU2, 2 * Y.R2, 0); seg(Y.T1, 2 * r, 0); }   // rotated Grams; V^T (d h), U^T (v / d)
+            else if (phase == 2) { seg(Y.ATU, 4 * r, 0); seg(Y.SC, 2, 0); }
+            else if (phase == 3) seg(Y.SC + 2, 2, 1);
+            else if (phase != 4) return PSGDK_ERR_INVALID;
+        } else if (kind == 1) {
+            if (phase == 0) seg(Y.VTX2, r, 0);
+            else if (phase == 1) seg(Y.UTY, r, 0);
+            else if (phase == 2) seg(Y.SC + 7, 1, 0);
+            else return PSGDK_ERR_INVALID;
+        } else return PSGDK_ERR_INVALID;
+        *n_segments = n;
+        return PSGDK_OK;
+    }
 #define LRA_SEGS(TPR_)                                                                                                    \
     { using C = LraCfg<TPR_>;                                                                                              \
       if (kind == 0) {                                                                                                     \

@@ -274,8 +274,6 @@ class LRAWhiten:
             if min(every) <= r:
                 raise ValueError(f"shard_rows: {N} rows over {world} ranks leaves a rank with {min(every)} rows for rank-{r} factors; "
                                  "use fewer ranks or replicas")
-            if r > 64:
-                raise NotImplementedError("shard_rows: the phased engine covers the tuned rank classes (r <= 64)")
             self._shard = dict(world=world, rank=rank, row0=row0, rows=rows, group=process_group, driver=None)
             self._gen = torch.Generator().manual_seed(int(seed))
         n_local = self._shard["rows"] if self._shard else N

@@ -32,7 +32,7 @@ def _state(N, r, dt, seed=5):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("r", [0, 10, 24, 48])
+@pytest.mark.parametrize("r", [0, 10, 24, 48, 80, 130])      # (80, 130: the general path above rank 64, cut into the same phases in round 6)
 @pytest.mark.parametrize("philox", [False, True])
 def test_phases_back_to_back_are_the_one_call_forms(dt, r, philox):
     from psgd_torch_amd import lra
@@ -101,7 +101,7 @@ def _functional_worker(rank, world, port, outdir, N, r):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("r", [10, 24])
+@pytest.mark.parametrize("r", [10, 24, 80])
 def test_two_ranks_one_gpu_match_one_gpu_with_the_engines_own_noise(r):
     from psgd_torch_amd import lra
     N, world = 6000 + 91, 2
