@@ -73,6 +73,7 @@ struct psgdk_plan {
     bool nlb_coop = false;            // the cooperative one-launch norm bound is usable for this plan
     bool nlb_small = false;           // ... in its instantiation for plans whose widest factor is <= 128 (one workgroup per factor, 16 columns per wave)
     bool nlb_k32 = false;             // ... factors of 25 .. 32 K steps (bf16 d <= 1024, fp32 d <= 512): members of 128 columns with 32 K steps of registers
+    int nlb_cols = 256;               // columns of A per member of the cooperative bound: 128 (nlb_small / nlb_narrow), 192 (twelve waves: round 6), 256
     bool nlb_narrow = false;          // ... with 128 columns of A per member instead of 256 (round 6): plans with few wide factors -- a rank's share
                                       //     of a sharded job, a model of a few layers -- whose 2 x as many members still fit the CUs
     NlbJob* d_nlb_jobs = nullptr; unsigned n_nlb_jobs = 0, nlb_lds = 0;
@@ -1107,9 +1108,11 @@ static int nlb_plan_coop(psgdk_plan* P) {
     // product half as many matrix instructions, a published piece half the stores: tools/nlb_stamps.py), members of 256 otherwise.
     // PSGDK_NLB_NARROW=0 keeps the wide members (the GPU suite compares the two on one plan).
     const char* env_narrow = getenv("PSGDK_NLB_NARROW");
-    for (int cols_per_wg : {128, 256}) {
-        if (cols_per_wg == 128 && !P->nlb_small && !P->nlb_k32 && env_narrow && env_narrow[0] == '0') continue;
-        if (cols_per_wg == 256 && P->nlb_k32) break;
+    // (round 6, second step) members of 192 columns -- twelve waves of 16 -- for the plans in between: GPT-2-small's 62 factors of 768 make 248
+    // workgroups of four members each, where members of 128 would need 372
+    for (int cols_per_wg : {128, 192, 256}) {
+        if (cols_per_wg < 256 && !P->nlb_small && !P->nlb_k32 && env_narrow && env_narrow[0] == '0') continue;
+        if (cols_per_wg > 128 && (P->nlb_k32 || P->nlb_small)) break;
         for (auto& l : xcd) l.clear();
         for (int f : order) {
             const int S = (P->dn[f].dp + cols_per_wg - 1) / cols_per_wg;
@@ -1119,8 +1122,7 @@ static int nlb_plan_coop(psgdk_plan* P) {
         }
         len = 0;
         for (auto& l : xcd) len = std::max(len, l.size());
-        if (len <= (size_t)(cus / 8)) { P->nlb_narrow = cols_per_wg == 128 && !P->nlb_small; break; }
-        if (P->nlb_small) break;
+        if (len <= (size_t)(cus / 8)) { P->nlb_narrow = cols_per_wg == 128 && !P->nlb_small; P->nlb_cols = cols_per_wg; break; }
     }
     if (len > (size_t)(cus / 8)) return PSGDK_OK;
     std::vector<NlbJob> jobs(8 * len, NlbJob{-1, 0, 0, 0});
@@ -1154,7 +1156,9 @@ static int nlb_plan_coop(psgdk_plan* P) {
                           (const void*)nlb_coop_kernel<bf16_t, 1, 4, true>, (const void*)nlb_coop_kernel<float, 1, 8, true>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 24>, (const void*)nlb_coop_kernel<float, 1, 24>,
                           (const void*)nlb_coop_kernel<bf16_t, 1, 24, true>, (const void*)nlb_coop_kernel<float, 1, 24, true>,
-                          (const void*)nlb_coop_kernel<bf16_t, 1, 32>, (const void*)nlb_coop_kernel<float, 1, 32>})
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 32>, (const void*)nlb_coop_kernel<float, 1, 32>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 24, false, 12>, (const void*)nlb_coop_kernel<float, 1, 24, false, 12>,
+                          (const void*)nlb_coop_kernel<bf16_t, 1, 24, true, 12>, (const void*)nlb_coop_kernel<float, 1, 24, true, 12>})
         HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     P->nlb_coop = !P->nlb_unfused;      // (the job table exists either way: psgdk_test_nlb runs both routes on one plan)
     return PSGDK_OK;
@@ -1166,9 +1170,11 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
         const bool bf = P->dtype == PSGDK_BF16;
         if (stamps && P->nlb_k32) return PSGDK_ERR_UNSUPPORTED;      // (no instrumented instantiation of the 32-K-step variant)
         const void* k = stamps ? (P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4, true> : (const void*)nlb_coop_kernel<float, 1, 8, true>)
+                                  : P->nlb_cols == 192 ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24, true, 12> : (const void*)nlb_coop_kernel<float, 1, 24, true, 12>)
                                   : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24, true> : (const void*)nlb_coop_kernel<float, 1, 24, true>)
                                                   : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24, true> : (const void*)nlb_coop_kernel<float, 2, 24, true>))
                       : P->nlb_small ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 4> : (const void*)nlb_coop_kernel<float, 1, 8>)
+                      : P->nlb_cols == 192 ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24, false, 12> : (const void*)nlb_coop_kernel<float, 1, 24, false, 12>)
                       : P->nlb_k32 ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 32> : (const void*)nlb_coop_kernel<float, 1, 32>)
                       : P->nlb_narrow ? (bf ? (const void*)nlb_coop_kernel<bf16_t, 1, 24> : (const void*)nlb_coop_kernel<float, 1, 24>)
                                       : (bf ? (const void*)nlb_coop_kernel<bf16_t, 2, 24> : (const void*)nlb_coop_kernel<float, 2, 24>);
@@ -1176,7 +1182,7 @@ static int run_nlb(psgdk_plan* P, int chain, const void* const* noise, uint64_t 
         unsigned char* state = P->state; unsigned char* work = P->work;
         void* args[] = {&dn, &jobs, &err, &state, &work, &chain, &noise, &seed, &offset, &lr, &betaL, &add_c, &pro_iter, &fault};
         ++g_psgdk_launches;
-        HIPCHK(hipLaunchKernel(k, dim3(P->n_nlb_jobs), dim3(512), args, P->nlb_lds, st));
+        HIPCHK(hipLaunchKernel(k, dim3(P->n_nlb_jobs), dim3(P->nlb_cols == 192 ? 768 : 512), args, P->nlb_lds, st));
         return PSGDK_OK;
     }
     DISPATCH_T(P, hipLaunchKernelGGL(nlb_init_kernel<T>, dim3(8, F), dim3(256), 0, st, P->d_dn, P->work, chain, noise, seed, offset, pro_iter));
@@ -1973,7 +1979,7 @@ int psgdk_plan_info(const psgdk_plan* plan, int what, int64_t* value) {
         case PSGDK_INFO_HSUMSQ_OFFSET: *value = (int64_t)plan->hsumsq_off; return PSGDK_OK;
         case PSGDK_INFO_BALNORM_OFFSET: *value = (int64_t)plan->balnorm_off; return PSGDK_OK;
         case PSGDK_INFO_UPDATE_FUSED: *value = plan->h_fused ? (int64_t)plan->n_fix : 0; return PSGDK_OK;
-        case PSGDK_INFO_NLB_MEMBER_COLS: *value = !plan->nlb_coop ? 0 : ((plan->nlb_small || plan->nlb_narrow) ? 128 : 256); return PSGDK_OK;
+        case PSGDK_INFO_NLB_MEMBER_COLS: *value = !plan->nlb_coop ? 0 : (plan->nlb_small ? 128 : plan->nlb_cols); return PSGDK_OK;
     }
     return PSGDK_ERR_INVALID;
 }
