@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PSGDK_VERSION 403    /* round 6 (403): psgdk_flat_set_clip_groups / psgdk_flat_apply_groups, psgdk_export_precond_grad clip = 2 (deferred clip of row shards),
+#define PSGDK_VERSION 404    /* round 6 (404): psgdk_lra_info (which row kernels the last LRA call took);
+                                round 6 (403): psgdk_flat_set_clip_groups / psgdk_flat_apply_groups, psgdk_export_precond_grad clip = 2 (deferred clip of row shards),
                                 row shards for the QEQ / QUAD geometries, PSGDK_INFO_NLB_MEMBER_COLS;
                                 round 6 (402): psgdk_precond_grad_apply (the parameter update fused into the apply's last product);
                                 round 5 (401): row shards of the LRA preconditioner (psgdk_lra_set_row_shard, psgdk_lra_update_phase / _apply_phase / _phase_segments);
@@ -285,6 +286,14 @@ int psgdk_lra_update_whiten(psgdk_lra* lra, const void* g, const void* v_noise, 
 int psgdk_lra_precond_grad(psgdk_lra* lra, const void* g, void* out, void* stream);
 /* device word holding the sum of squares of the last psgdk_lra_precond_grad output (see psgdk_flat_apply_clipped) */
 int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr);
+/* What the last psgdk_lra_update_* / psgdk_lra_precond_grad / _apply_phase call did (host-side bookkeeping, no device access):
+ *   PSGDK_LRA_INFO_PACKED_ROWS  rows covered by the two-rows-per-thread bf16 kernels (csrc/kernels_lra_pk.hiph: bf16 factors, even rank
+ *                               2 .. 16, N >= 512, 4-byte aligned N-vectors): floor(N / 512) * 512, or 0 when the one-row kernels ran
+ *                               everything (also with PSGDK_LRA_PK=0 in the environment, the A/B switch of the tests);
+ *   PSGDK_LRA_INFO_GRAM_AGE     updates since the carried Grams were last read from the factors (-1: not valid / recurrence off). */
+#define PSGDK_LRA_INFO_PACKED_ROWS 0
+#define PSGDK_LRA_INFO_GRAM_AGE 1
+int psgdk_lra_info(const psgdk_lra* lra, int what, int64_t* value);
 
 /* ---- row shards of ONE LRA preconditioner (last row; new relative to the reference, whose LRA runs replicas only).
  * U, V, d are cut by rows over the ranks: an object created with N = the shard's row count and declared by psgdk_lra_set_row_shard(row0)

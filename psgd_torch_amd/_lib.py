@@ -9,11 +9,12 @@ LIB_PATH = os.path.join(_HERE, "libpsgdk.so")
 PSGDK_OK, PSGDK_ERR_INVALID, PSGDK_ERR_UNSUPPORTED, PSGDK_ERR_HIP, PSGDK_ERR_STATE, PSGDK_ERR_NLB_TIMEOUT = 0, 1, 2, 3, 4, 5
 INFO_NLB_COOP, INFO_NLB_FALLBACKS, INFO_DENSE_FACTORS, INFO_MAX_DENSE_DIM, INFO_HSUMSQ_OFFSET, INFO_BALNORM_OFFSET, INFO_UPDATE_FUSED = 0, 1, 2, 3, 4, 5, 6
 INFO_NLB_MEMBER_COLS = 7
+LRA_INFO_PACKED_ROWS, LRA_INFO_GRAM_AGE = 0, 1
 BF16, F32 = 0, 1
 DIAG, DENSE, SCALAR = 0, 1, 2
 GEOM_Q0P5EQ1P5, GEOM_EQ, GEOM_QEQ, GEOM_QUAD, GEOM_QEP, GEOM_QUAD4P, GEOM_PRO4P = 0, 1, 2, 3, 4, 5, 6
 SRC_EMA, SRC_GRAD = 0, 1
-ABI_VERSION = 403      # PSGDK_VERSION this binding was written against (checked at load)
+ABI_VERSION = 404      # PSGDK_VERSION this binding was written against (checked at load)
 MAX_DIMS = 26          # PSGDK_MAX_DIMS: noise pointer slots per tensor (include/psgdk.h)
 
 
@@ -112,6 +113,7 @@ SIGNATURES = {
     "psgdk_flat_apply_clipped": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
                                            C.c_float, C.c_float, C.c_void_p]),
     "psgdk_lra_last_sumsq": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "psgdk_lra_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "psgdk_lra_set_row_shard": (C.c_int, [C.c_void_p, C.c_int64]),
     "psgdk_lra_update_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_float, C.c_float,
                                          C.c_float, C.c_void_p]),

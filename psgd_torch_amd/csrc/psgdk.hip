@@ -9,6 +9,7 @@
 #include "kernels_ew.hiph"
 #include "kernels_dense.hiph"
 #include "kernels_lra.hiph"
+#include "kernels_lra_pk.hiph"
 #include "kernels_lra_gen.hiph"
 #include "kernels_gen.hiph"
 #include "kernels_eq.hiph"
@@ -2396,8 +2397,81 @@ struct psgdk_lra {
     float* gst = nullptr;      // device: [UtU | VtV | VtU | rotated VtU of the update in flight], 4 x RM x RM fp32
     int gram_every = 0;        // 0 = off: every update reads the factors for its Grams (psgd.py:1006 as written)
     int gram_age = -1;         // updates since the Grams in gst were last read from the factors; -1 = gst is not valid
+    int64_t pk_rows = 0;       // rows the packed two-rows-per-thread kernels (kernels_lra_pk.hiph) covered in the last update / apply call (0: none)
     ~psgdk_lra() { if (gst) (void)hipFree(gst); }
 };
+
+// The launches of kernels_lra_pk.hiph (bf16 factors of even rank <= 16, one thread per row pair): the packed kernels over the first
+// floor(N / 512) * 512 rows, the one-row kernels of kernels_lra.hiph over the tail (their partial sums meet in the same scratch slots).
+// false = not this instantiation: the caller goes on to the one-row kernels for everything.
+// (the packed kernels are instantiated for the even rank itself, RE: every request of a block is then a whole access of every thread)
+#define LRAPK_RE(r_, ...) do { switch (r_) { case 2: { constexpr int RE = 2; __VA_ARGS__; } break; case 4: { constexpr int RE = 4; __VA_ARGS__; } break; \
+                                             case 6: { constexpr int RE = 6; __VA_ARGS__; } break; case 8: { constexpr int RE = 8; __VA_ARGS__; } break;  \
+                                             case 10: { constexpr int RE = 10; __VA_ARGS__; } break; case 12: { constexpr int RE = 12; __VA_ARGS__; } break; \
+                                             case 14: { constexpr int RE = 14; __VA_ARGS__; } break; default: { constexpr int RE = 16; __VA_ARGS__; } break; } } while (0)
+struct LrapkGeom { unsigned gb1, gb2, gbr, shm1, shm2, shmr;        // packed kernels: grids / dynamic LDS for one factor, two, the rotation
+                   unsigned tb1, tb2, tbr, tshm1, tshm2, tshmr;     // tail, one-row kernels
+                   int64_t nf; };                                   // rows the packed kernels own
+template <typename T, int TPR, int RC>
+static bool lrapk_update_phase(psgdk_lra* L, int phase, const LrapkGeom& G, T* U, T* V, T* d, const LraVH<T>& vh, T* Qh, T* iq, T* diff, float* sm,
+                               unsigned shm_s1, bool recur, bool grams_carried, int update_u, float lr, float betaL, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && TPR == 1) {
+        const int64_t N = L->N, nf = G.nf, nt = N - nf; const int r = L->r;
+        LraVH<T> vt = vh;           // the tail's rows: the same vectors from row nf on (Philox counters of the WHOLE vector)
+        vt.g = vh.g + nf; vt.noise = vh.noise ? vh.noise + nf : nullptr; vt.row0 = vh.row0 + nf;
+        T* Ut = U + nf * r; T* Vt = V + nf * r;
+        switch (phase) {
+        case 1:
+            hipLaunchKernelGGL((lra_small1_kernel<T, TPR>), dim3(1), dim3(256), shm_s1, st, sm, r, recur ? L->gst + 3 * LraCfg<TPR>::MS : (float*)nullptr);
+            LRAPK_RE(r, hipLaunchKernelGGL((lrapk_rotate_kernel<RE>), dim3(G.gbr), dim3(LRA_THREADS), G.shmr, st, U, V, (const T*)d, vh, nf, r, sm));
+            if (nt) hipLaunchKernelGGL((lra_rotate_kernel<T, TPR, RC>), dim3(G.tbr), dim3(LRA_THREADS), G.tshmr, st, Ut, Vt, (const T*)(d + nf), vt, nt, r, sm);
+            break;
+        case 2:
+            hipLaunchKernelGGL((lra_small2_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+            LRAPK_RE(r, hipLaunchKernelGGL((lrapk_pass3_kernel<RE>), dim3(G.gb2), dim3(LRA_THREADS), G.shm2, st, (const T*)U, (const T*)V, (const T*)d, vh, Qh, iq, nf, r, sm));
+            if (nt) hipLaunchKernelGGL((lra_pass3_kernel<T, TPR, RC>), dim3(G.tb2), dim3(LRA_THREADS), G.tshm2, st, (const T*)Ut, (const T*)Vt, (const T*)(d + nf), vt,
+                                       Qh + nf, iq + nf, nt, r, sm);
+            break;
+        case 3:
+            hipLaunchKernelGGL((lra_small3_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, r);
+            LRAPK_RE(r, hipLaunchKernelGGL((lrapk_pass4_kernel<RE>), dim3(G.gb2), dim3(LRA_THREADS), G.shm2, st, (const T*)U, (const T*)V, (const T*)d, vh, (const T*)Qh,
+                               (const T*)iq, diff, nf, r, sm));
+            if (nt) hipLaunchKernelGGL((lra_pass4_kernel<T, TPR, RC>), dim3(G.tb2), dim3(LRA_THREADS), G.tshm2, st, (const T*)Ut, (const T*)Vt, (const T*)(d + nf), vt,
+                                       (const T*)(Qh + nf), (const T*)(iq + nf), diff + nf, nt, r, sm);
+            break;
+        case 4:
+            hipLaunchKernelGGL((lra_small4_kernel<T, TPR>), dim3(1), dim3(64), 0, st, sm, L->Luvd, r, update_u ? 1 : 0, lr, betaL);
+            LRAPK_RE(r, hipLaunchKernelGGL((lrapk_pass5_kernel<RE>), dim3(G.gb1), dim3(LRA_THREADS), G.shm1, st, U, V, d, (const T*)Qh, (const T*)iq, (const T*)diff, nf, r,
+                               update_u ? 1 : 0, (const float*)sm));
+            if (nt) hipLaunchKernelGGL((lra_pass5_kernel<T, TPR, RC>), dim3(G.tb1), dim3(LRA_THREADS), G.tshm1, st, Ut, Vt, d + nf, (const T*)(Qh + nf),
+                                       (const T*)(iq + nf), (const T*)(diff + nf), nt, r, update_u ? 1 : 0, (const float*)sm);
+            if (recur) {      // the Grams of the factors as pass 5 leaves them, for the next update
+                hipLaunchKernelGGL((lra_gram_recur_kernel<T, TPR>), dim3(1), dim3(256), 0, st, (const float*)sm, (const float*)(L->gst + 3 * LraCfg<TPR>::MS),
+                                   L->gst, r, update_u ? 1 : 0);
+                L->gram_age = grams_carried ? L->gram_age + 1 : 1;
+            }
+            break;
+        default:
+            return false;      // (phase 0, the Grams, keeps its kernel: it runs once in `gram_every` updates)
+        }
+        return true;
+    } else {
+        return false;
+    }
+}
+template <typename T, int TPR, int RC>
+static bool lrapk_apply_phase(psgdk_lra* L, int phase, const LrapkGeom& G, const T* g, T* y, T* out, float* sm, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && TPR == 1) {
+        const int64_t nf = G.nf, nt = L->N - nf; const int r = L->r;
+        const T* U = (const T*)L->U; const T* V = (const T*)L->V; const T* d = (const T*)L->d;
+        LRAPK_RE(r, hipLaunchKernelGGL((lrapk_apply_kernel<RE>), dim3(G.gb1), dim3(LRA_THREADS), G.shm1, st, U, V, d, g, y, out, nf, r, phase, sm));
+        if (nt) hipLaunchKernelGGL((lra_apply_kernel<T, TPR, RC>), dim3(G.tb1), dim3(LRA_THREADS), G.tshm1, st, U + nf * r, V + nf * r, d + nf, g + nf, y + nf,
+                                   out + nf, nt, r, phase, sm);
+        return true;
+    } else {
+        return false;
+    }
+}
 
 extern "C" {
 
@@ -2472,6 +2546,34 @@ static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* g
     const int64_t blocks = (N + rows - 1) / rows;
     *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * (int64_t)per_cu));
     *shm = bytes;
+}
+
+// the packed two-rows-per-thread passes (kernels_lra_pk.hiph): bf16 factors, one thread per row pair, 512 rows per workgroup and iteration
+static void lrapk_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm) {
+    const unsigned bytes = (unsigned)std::max(16, mats * LRAPK_ROWS * r * 2);
+    const unsigned per_cu = std::max(1u, std::min(8u, (160u * 1024u) / (bytes + fixed + 1024u)));
+    const int64_t blocks = (N + LRAPK_ROWS - 1) / LRAPK_ROWS;
+    *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * (int64_t)per_cu));
+    *shm = bytes;
+}
+// ... taken when every N-vector the passes touch can be read two elements at a time (PSGDK_LRA_PK=0: the one-row kernels, for A/B runs and tests)
+static void lra_geometry(int64_t N, int r, int mats, unsigned fixed, unsigned* grid, unsigned* shm);
+static LrapkGeom lrapk_geom(int64_t N, int r) {
+    LrapkGeom G{};
+    G.nf = (N / LRAPK_ROWS) * LRAPK_ROWS;
+    const int64_t nt = N - G.nf;
+    const unsigned rot_fixed = 2u * 16u * 16u * 4u;
+    lrapk_geometry(G.nf, r, 1, 0, &G.gb1, &G.shm1); lrapk_geometry(G.nf, r, 2, 0, &G.gb2, &G.shm2); lrapk_geometry(G.nf, r, 2, rot_fixed, &G.gbr, &G.shmr);
+    if (nt) { lra_geometry(nt, r, 1, 0, &G.tb1, &G.tshm1); lra_geometry(nt, r, 2, 0, &G.tb2, &G.tshm2); lra_geometry(nt, r, 2, rot_fixed, &G.tbr, &G.tshmr); }
+    return G;
+}
+static bool lrapk_ok(const psgdk_lra* L, const void* a, const void* b, const void* c) {
+    if (L->dtype != PSGDK_BF16 || L->r < 2 || L->r > 16 || (L->r & 1) || L->N < LRAPK_ROWS) return false;
+    const char* e = getenv("PSGDK_LRA_PK");
+    if (e && e[0] == '0') return false;
+    const uintptr_t vec = (uintptr_t)L->d | (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)L->work;
+    const uintptr_t mat = (uintptr_t)L->U | (uintptr_t)L->V;
+    return (vec & 3) == 0 && (mat & 15) == 0;
 }
 
 // ranks above 64: the general path (kernels_lra_gen.hiph), stage for stage the tuned one
@@ -2575,11 +2677,19 @@ static int lra_update_phase_t(psgdk_lra* L, int phase, const void* g, const void
     // their sums run over the ranks)
     const bool recur = L->gram_every > 0 && r > 0 && !L->sharded && L->gst != nullptr;
     const bool grams_carried = recur && L->gram_age >= 0 && L->gram_age < L->gram_every;
+    const bool pk = lrapk_ok(L, g, v_noise, nullptr);
+    const LrapkGeom pkg = pk ? lrapk_geom(N, r) : LrapkGeom{};
+    L->pk_rows = pk ? pkg.nf : 0;
     LRA_T(L, {
         T* Qh = (T*)(L->work + L->qh_off); T* iq = (T*)(L->work + L->iq_off); T* diff = (T*)(L->work + L->diff_off);
         T* U = (T*)L->U; T* V = (T*)L->V; T* d = (T*)L->d;
         // (no preparation pass: v and h are rebuilt from g where they are used -- LraVH)
         const LraVH<T> vh{(const T*)g, (const T*)v_noise, damping, seed, offset, L->row0};
+        if (pk && phase >= 1 &&
+            lrapk_update_phase<T, TPR, RC>(L, phase, pkg, U, V, d, vh, Qh, iq, diff, sm, shm_s1, recur, grams_carried, update_u, lr, betaL, st)) {
+            HIPCHK(hipGetLastError());
+            return PSGDK_OK;
+        }
         switch (phase) {
         case 0:
             if (grams_carried)      // UTU, VTV, VTU are the first three matrices of the scratch block, in gst's order
@@ -2630,9 +2740,16 @@ static int lra_apply_phase_t(psgdk_lra* L, int phase, const void* g, void* out, 
     float* sm = (float*)(L->work + L->sm_off);
     unsigned gb1, shm1;
     lra_geometry(L->N, L->r, 1, 0, &gb1, &shm1);
+    const bool pk = lrapk_ok(L, g, out, nullptr);
+    const LrapkGeom pkg = pk ? lrapk_geom(L->N, L->r) : LrapkGeom{};
+    L->pk_rows = pk ? pkg.nf : 0;
     LRA_T(L, {
         if (phase == 0) HIPCHK(hipMemsetAsync(sm + LraCfg<TPR>::HSQ, 0, (size_t)(LraCfg<TPR>::TOTAL - LraCfg<TPR>::HSQ) * 4, st));
         T* y = (T*)(L->work + L->y_off);
+        if (pk && lrapk_apply_phase<T, TPR, RC>(L, phase, pkg, (const T*)g, y, (T*)out, sm, st)) {
+            HIPCHK(hipGetLastError());
+            return PSGDK_OK;
+        }
         hipLaunchKernelGGL((lra_apply_kernel<T, TPR, RC>), dim3(gb1), dim3(LRA_THREADS), shm1, st, (const T*)L->U, (const T*)L->V, (const T*)L->d,
                            (const T*)g, y, (T*)out, L->N, L->r, phase, sm);
     });
@@ -2749,6 +2866,15 @@ int psgdk_lra_last_sumsq(const psgdk_lra* lra, const float** dev_ptr) {
     const int tpr = lra_tpr_of_rank(lra->r);
     *dev_ptr = (const float*)(lra->work + lra->sm_off) + (tpr == 1 ? LraCfg<1>::HSQ : (tpr == 2 ? LraCfg<2>::HSQ : LraCfg<4>::HSQ));
     return PSGDK_OK;
+}
+
+int psgdk_lra_info(const psgdk_lra* lra, int what, int64_t* value) {
+    if (!lra || !value) return PSGDK_ERR_INVALID;
+    switch (what) {
+    case PSGDK_LRA_INFO_PACKED_ROWS: *value = lra->pk_rows; return PSGDK_OK;
+    case PSGDK_LRA_INFO_GRAM_AGE: *value = lra->gram_age; return PSGDK_OK;
+    default: return PSGDK_ERR_INVALID;
+    }
 }
 
 }  // extern "C"

@@ -71,6 +71,15 @@ class _LraEngine:
         base = self.keep[3]
         return all(isinstance(x, torch.Tensor) and x.data_ptr() == base[i].data_ptr() for i, x in enumerate(Luvd))
 
+    def info(self) -> dict:
+        """Which row kernels the last update / apply call took (psgdk_lra_info)."""
+        out = {}
+        for name, code in (("packed_rows", L.LRA_INFO_PACKED_ROWS), ("gram_age", L.LRA_INFO_GRAM_AGE)):
+            v = C.c_int64()
+            L.check(self.lib.psgdk_lra_info(self.h, code, C.byref(v)), "lra_info")
+            out[name] = int(v.value)
+        return out
+
     def last_sumsq_ptr(self):
         """Device word with the sum of squares of the last precond_grad output (the RMS clip reads it on the device)."""
         p = C.c_void_p()

@@ -345,3 +345,82 @@ def test_lra_vit_b_true_n_r10():
     except ImportError:
         pass
     _lra_case(86_543_080, 10, steps=1, seed=1)
+
+
+def _lra_case_bf16(N, r, steps=2, seed=0, with_bf16_oracle=True):
+    """bf16 factors (the reference's LRAWhiten keeps U, V, d in the parameter dtype: psgd.py:1118-1128) on the HIP path vs the fp64 oracle on
+    the SAME bf16-rounded inputs; the yardstick is the oracle run in bf16 (torch CPU bf16 arithmetic = what the reference would compute):
+    HIP error <= 1.5 x its error + one bf16 ulp.  Without the bf16 oracle (true N: host memory): absolute bounds a few ulp wide."""
+    amd = _amd()
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    g = torch.Generator().manual_seed(190 + seed)
+    bf = torch.bfloat16
+    U0 = torch.randn(N, r, generator=g)
+    U0 *= 0.1 ** 0.5 / float(torch.linalg.vector_norm(U0))
+    U0 = U0.to(bf)
+    V0 = torch.randn(N, r, generator=g)
+    V0 *= 0.1 ** 0.5 / float(torch.linalg.vector_norm(V0))
+    V0 = V0.to(bf)
+    d0 = (0.5 + torch.rand(N, 1, generator=g)).to(bf)
+    hscale = 0.5 + 2 * torch.rand(N, 1, generator=g)
+    UVd = [U0.clone().to(DEV), V0.clone().to(DEV), d0.clone().to(DEV)]
+    Luvd = [torch.zeros([], dtype=torch.float32, device=DEV) for _ in range(3)]
+    UVd64 = [U0.double(), V0.double(), d0.double()]
+    Luvd64 = [torch.zeros([], dtype=torch.float64) for _ in range(3)]
+    UVdb = [U0.clone(), V0.clone(), d0.clone()] if with_bf16_oracle else None
+    Luvdb = [torch.zeros([], dtype=bf) for _ in range(3)]
+    for t in range(steps):
+        gt = (hscale * torch.randn(N, 1, generator=g)).to(bf)
+        vn = torch.randn(N, 1, generator=g).to(bf)
+        coin = 0.25 if t % 2 == 0 else 0.75
+        amd.update_precond_lra_whiten(UVd, Luvd, gt.to(DEV), lr=0.1, betaL=0.9, damping=1e-9, v_noise=vn.to(DEV), coin=coin)
+        assert UVd[2]._psgdk_lra.info()["packed_rows"] == (N // 512 * 512 if (r % 2 == 0 and 2 <= r <= 16) else 0)
+        h = amd.precond_grad_lra(UVd, gt.to(DEV))
+        orc.update_precond_lra_whiten(UVd64, Luvd64, gt.double(), vn.double(), coin, lr=0.1, betaL=0.9, damping=1e-9)
+        h64 = orc.precond_grad_lra(UVd64, gt.double())
+        if with_bf16_oracle:
+            orc.update_precond_lra_whiten(UVdb, Luvdb, gt, vn, coin, lr=0.1, betaL=0.9, damping=1e-9)
+            hb = orc.precond_grad_lra(UVdb, gt)
+            refs = (hb, UVdb[0], UVdb[1], UVdb[2])
+        else:
+            refs = (None,) * 4
+        for what, got, truth, ref in zip(("h", "U", "V", "d"), (h, UVd[0], UVd[1], UVd[2]), (h64, UVd64[0], UVd64[1], UVd64[2]), refs):
+            assert torch.isfinite(got.float()).all()
+            e = relerr(got, truth)
+            if ref is not None:
+                e_ref = relerr(ref, truth)
+                assert e <= 1.5 * e_ref + ULP, (N, r, t, what, e, e_ref)
+            else:
+                assert e <= 2.5 * ULP * (t + 1), (N, r, t, what, e)
+        for k in range(3):
+            e = relerr(Luvd[k], Luvd64[k])
+            if with_bf16_oracle:
+                assert e <= 1.5 * relerr(Luvdb[k], Luvd64[k]) + 2 * ULP, (N, t, "L", k, e)
+            else:
+                assert e <= 5 * ULP, (N, t, "L", k, e)
+    assert relerr(UVd64[0], U0.double()) > 1e-3 or relerr(UVd64[1], V0.double()) > 1e-3
+
+
+@pytest.mark.parametrize("r", [10, 16, 4])
+def test_lra_bf16_vit_b_scale_n2e7(r):
+    """ViT-B/16-scale LRA in bf16 (SURVEY section 8d quotes config 4 in both dtypes), N = 2*10^7 ragged, on the packed two-rows-per-thread
+    kernels (kernels_lra_pk.hiph; the 387-row tail on the one-row kernels) vs the fp64 oracle, yardstick: the oracle in bf16
+    (psgd.py:994-1072)."""
+    _lra_case_bf16(20_000_387, r, steps=2, seed=r)
+
+
+def test_lra_bf16_odd_rank_n3e6():
+    """an odd rank keeps the one-row kernels (bf16)"""
+    _lra_case_bf16(3_000_017, 7, steps=2, seed=7)
+
+
+def test_lra_bf16_vit_b_true_n_r10():
+    """The true ViT-B/16 N = 86,543,080 in bf16, r = 10, one update + apply vs the fp64 oracle (absolute bounds: no bf16 oracle at this
+    size, host memory)."""
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 40 * 2 ** 30:
+            pytest.skip("not enough host memory for the fp64 oracle at N = 86.5 M")
+    except ImportError:
+        pass
+    _lra_case_bf16(86_543_080, 10, steps=1, seed=1, with_bf16_oracle=False)

@@ -171,3 +171,105 @@ def test_gram_recurrence_notices_a_factor_written_by_somebody_else():
         res.append([x.cpu() for x in UVd])
     for x, y in zip(*res):
         assert relerr(x, y) <= 1e-6, relerr(x, y)
+
+
+def _pk_inputs(N, r, seed):
+    gen = torch.Generator().manual_seed(1000 * r + seed)
+    bf = torch.bfloat16
+    U0 = torch.randn(N, r, generator=gen); U0 *= 0.1 ** 0.5 / torch.linalg.vector_norm(U0)
+    V0 = torch.randn(N, r, generator=gen); V0 *= 0.1 ** 0.5 / torch.linalg.vector_norm(V0)
+    d0 = 0.5 + torch.rand(N, 1, generator=gen)
+    scale = torch.linspace(0.3, 2.5, N).reshape(N, 1)
+    gs = [(torch.randn(N, 1, generator=gen) * scale).to(bf) for _ in range(3)]
+    vs = [torch.randn(N, 1, generator=gen).to(bf) for _ in range(3)]
+    return U0.to(bf), V0.to(bf), d0.to(bf), gs, vs
+
+
+def _pk_run(U0, V0, d0, gs, vs, coins=(0.2, 0.8, 0.2), offset_by_one_element=False):
+    """Three updates (both branches of the U-or-V coin) + an apply after each on the HIP path; returns the host copies and what
+    psgdk_lra_info said about the row kernels of the last call."""
+    from psgd_torch_amd import lra
+    UVd = [U0.to(DEV).contiguous(), V0.to(DEV).contiguous(), d0.to(DEV).contiguous()]
+    Luvd = [torch.zeros([], dtype=torch.float32, device=DEV) for _ in range(3)]
+    hs, packed = [], []
+    for g, v, c in zip(gs, vs, coins):
+        gd = g.to(DEV)
+        if offset_by_one_element:       # a gradient that starts 2 bytes into its allocation: the 32-bit N-vector accesses cannot be used
+            buf = torch.empty(g.numel() + 1, dtype=g.dtype, device=DEV)
+            buf[1:].copy_(gd.reshape(-1))
+            gd = buf[1:].reshape(g.shape)
+            assert gd.data_ptr() % 4 == 2 and gd.is_contiguous()
+        lra.update_precond_lra_whiten(UVd, Luvd, gd, lr=0.2, betaL=0.9, damping=1e-9, v_noise=v.to(DEV), coin=c)
+        packed.append(UVd[2]._psgdk_lra.info()["packed_rows"])
+        hs.append(lra.precond_grad_lra(UVd, gd).float().cpu())
+        packed.append(UVd[2]._psgdk_lra.info()["packed_rows"])
+    torch.cuda.synchronize()
+    return [x.float().cpu() for x in UVd], hs, [float(x) for x in Luvd], packed
+
+
+@pytest.mark.parametrize("r", [2, 4, 6, 8, 10, 12, 14, 16])
+@pytest.mark.parametrize("N", [512, 5 * 512, 7 * 512 + 301, 300_001])
+def test_packed_row_kernels_agree_with_the_one_row_kernels(N, r, monkeypatch):
+    """Round 6: kernels_lra_pk.hiph (bf16 factors of even rank <= 16: one thread per row PAIR, rows packed in LDS) against
+    kernels_lra.hiph on the same bf16 inputs -- every even rank the packed kernels are instantiated for, N = one block, whole blocks only,
+    blocks + a ragged tail (the tail runs on the one-row kernels, partial sums meet in the same scratch slots), and a size where every
+    workgroup loops.  PSGDK_LRA_PK=0 is the A/B switch.  The arithmetic of a row is the same in both; the reductions over rows sum in a
+    different order, so the outputs differ by roundings of bf16 stores: both must sit equally close to the fp64 oracle on the same inputs
+    (psgd.py:994-1072), and close to each other."""
+    U0, V0, d0, gs, vs = _pk_inputs(N, r, seed=N % 97)
+    monkeypatch.delenv("PSGDK_LRA_PK", raising=False)
+    a, ha, la, pa = _pk_run(U0, V0, d0, gs, vs)
+    assert pa == [N // 512 * 512] * 6, pa           # the packed kernels did run, over every whole block
+    monkeypatch.setenv("PSGDK_LRA_PK", "0")
+    b, hb, lb, pb = _pk_run(U0, V0, d0, gs, vs)
+    assert pb == [0] * 6, pb
+    U64 = [U0.double(), V0.double(), d0.double()]
+    L64 = [torch.zeros([], dtype=torch.float64) for _ in range(3)]
+    for t, (g, v, c) in enumerate(zip(gs, vs, (0.2, 0.8, 0.2))):
+        orc.update_precond_lra_whiten(U64, L64, g.double(), v.double(), c, lr=0.2, betaL=0.9, damping=1e-9)
+        h64 = orc.precond_grad_lra(U64, g.double())
+        e_pk, e_one = relerr(ha[t], h64), relerr(hb[t], h64)
+        assert torch.isfinite(ha[t]).all()
+        assert e_pk <= 1.25 * e_one + 2e-3, (N, r, t, "h", e_pk, e_one)
+        assert relerr(ha[t], hb[t]) <= 8e-3, (N, r, t, relerr(ha[t], hb[t]))
+    for nm, x, y, truth in zip(("U", "V", "d"), a, b, U64):
+        e_pk, e_one = relerr(x, truth), relerr(y, truth)
+        assert e_pk <= 1.25 * e_one + 2e-3, (N, r, nm, e_pk, e_one)
+        assert relerr(x, y) <= 8e-3, (N, r, nm, relerr(x, y))
+    for k in range(3):
+        assert abs(la[k] - lb[k]) <= 2e-2 * abs(lb[k]), (la, lb)
+        assert abs(la[k] - float(L64[k])) <= 1.25 * abs(lb[k] - float(L64[k])) + 1e-2 * abs(float(L64[k])), (k, la, lb, [float(x) for x in L64])
+
+
+def test_packed_row_kernels_eligibility():
+    """Who takes the packed kernels (include/psgdk.h PSGDK_LRA_INFO_PACKED_ROWS): bf16 AND even rank in 2..16 AND N >= 512 AND N-vectors on
+    4-byte boundaries.  Everything else runs the one-row kernels with unchanged results: a gradient 2 bytes into its allocation gives what
+    the aligned copy gives under PSGDK_LRA_PK=0 (the same kernels on the same values; the reductions over rows end in fp32 atomics, whose
+    order is the scheduler's: equal to fp32 rounding of the r-vectors, i.e. to a rare bf16 flip of a stored element)."""
+    from psgd_torch_amd import lra
+    for N, r, dt, want in ((4096, 10, torch.bfloat16, 4096), (4096, 9, torch.bfloat16, 0), (4096, 18, torch.bfloat16, 0),
+                           (511, 10, torch.bfloat16, 0), (4096, 10, torch.float32, 0), (4096 + 77, 4, torch.bfloat16, 4096)):
+        gen = torch.Generator().manual_seed(N + r)
+        UVd = [(0.01 * torch.randn(N, r, generator=gen)).to(dt).to(DEV), (0.01 * torch.randn(N, r, generator=gen)).to(dt).to(DEV),
+               torch.ones(N, 1, dtype=dt, device=DEV)]
+        Luvd = [torch.zeros([], dtype=torch.float32, device=DEV) for _ in range(3)]
+        g = torch.randn(N, 1, generator=gen).to(dt).to(DEV)
+        lra.update_precond_lra_whiten(UVd, Luvd, g, lr=0.1, betaL=0.9, damping=1e-9, v_noise=torch.randn(N, 1, generator=gen).to(dt).to(DEV), coin=0.1)
+        assert UVd[2]._psgdk_lra.info()["packed_rows"] == want, (N, r, dt)
+        h = lra.precond_grad_lra(UVd, g)
+        assert UVd[2]._psgdk_lra.info()["packed_rows"] == want, (N, r, dt)
+        assert torch.isfinite(h.float()).all()
+    U0, V0, d0, gs, vs = _pk_inputs(7 * 512 + 301, 10, seed=5)
+    a, ha, la, pa = _pk_run(U0, V0, d0, gs, vs, offset_by_one_element=True)
+    assert pa == [0] * 6, pa
+    import os
+    os.environ["PSGDK_LRA_PK"] = "0"
+    try:
+        b, hb, lb, pb = _pk_run(U0, V0, d0, gs, vs)
+    finally:
+        del os.environ["PSGDK_LRA_PK"]
+    for x, y in zip(a + ha, b + hb):
+        assert relerr(x, y) <= 1e-3, relerr(x, y)
+        assert float((x != y).float().mean()) <= 0.02
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-4 * abs(y), (la, lb)
