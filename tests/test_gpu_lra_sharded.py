@@ -75,7 +75,7 @@ def _free_port():
     return port
 
 
-def _functional_worker(rank, world, port, outdir, N, r):
+def _functional_worker(rank, world, port, outdir, N, r, dt=torch.float32):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -83,7 +83,7 @@ def _functional_worker(rank, world, port, outdir, N, r):
     try:
         from psgd_torch_amd import lra
         from psgd_torch_amd.lra_sharded import RowShardedLRA, all_gather_rows, shard_rows
-        U, V, d, gs, _ = _state(N, r, torch.float32)
+        U, V, d, gs, _ = _state(N, r, dt)
         row0, rows = shard_rows(N, world, rank)
         loc = slice(row0, row0 + rows)
         UVd = [U[loc].clone().to(DEV), V[loc].clone().to(DEV), d[loc].clone().to(DEV)]
@@ -95,10 +95,38 @@ def _functional_worker(rank, world, port, outdir, N, r):
             drv.update_whiten(gs[t][loc].to(DEV), lr=0.1, betaL=0.9, damping=1e-9, seed=11 + t, offset=t, update_u=(t % 2 == 0))
         h = all_gather_rows(drv.precond_grad(gs[3][loc].to(DEV)), N, world, rank)
         torch.cuda.synchronize()
-        torch.save(dict(U=UVd[0].cpu(), V=UVd[1].cpu(), d=UVd[2].cpu(), L=L3.cpu(), h=h.cpu(), n=drv.collectives),
+        torch.save(dict(U=UVd[0].cpu(), V=UVd[1].cpu(), d=UVd[2].cpu(), L=L3.cpu(), h=h.cpu(), n=drv.collectives, packed=eng.info()["packed_rows"], rows=rows),
                    os.path.join(outdir, f"r{rank}.pt"))
     finally:
         torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_bf16_packed_row_kernels():
+    """Round 6: the shards of a bf16 preconditioner of even rank <= 16 run the packed two-rows-per-thread kernels (kernels_lra_pk.hiph) over
+    their whole blocks, each with its own row0: the Philox counters of the damping noise run over the WHOLE vector, so a shard starting at an
+    odd multiple of anything must draw what one GPU draws for those rows (a wrong counter is an O(1) error in U, V, d).  Two ranks on one
+    GPU against the unsharded engine, bf16: agreement to the rounding of bf16 stores."""
+    from psgd_torch_amd import lra
+    N, world, r = 9000 + 91, 2, 10
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_functional_worker, args=(world, _free_port(), outdir, N, r, torch.bfloat16), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, f"r{k}.pt")) for k in range(world)]
+    for x in res:
+        assert x["packed"] == x["rows"] // 512 * 512 > 0, (x["packed"], x["rows"])
+    U, V, d, gs, _ = _state(N, r, torch.bfloat16)
+    UVd = [U.to(DEV), V.to(DEV), d.to(DEV)]
+    L3 = torch.zeros(3, dtype=torch.float32, device=DEV)
+    eng = lra._LraEngine(UVd, L3)
+    for t in range(3):
+        eng.update_whiten(gs[t].to(DEV), 0.1, 0.9, 1e-9, seed=11 + t, offset=t, update_u=(t % 2 == 0))
+    h = eng.precond_grad(gs[3].to(DEV))
+    torch.cuda.synchronize()
+    assert eng.info()["packed_rows"] == N // 512 * 512
+    assert torch.equal(res[0]["L"], res[1]["L"]) and torch.equal(res[0]["h"], res[1]["h"])
+    for k, nm in enumerate(("U", "V", "d")):
+        got = torch.cat([x[nm] for x in res])
+        assert relerr(got, UVd[k]) <= 1e-2, (nm, relerr(got, UVd[k]))
+    assert relerr(res[0]["L"], L3) <= 1e-2 and relerr(res[0]["h"], h) <= 1e-2
 
 
 @pytest.mark.parametrize("r", [10, 24, 80])
