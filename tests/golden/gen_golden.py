@@ -637,13 +637,13 @@ def gen_lra_case(name, N, r, dtypes, T=4, lr=0.1, betaL=0.9, damping=1e-9, seed=
     save(prefix + name, out)
 
 
-def gen_lrawhiten_case(name, T=4, seed=0, **kw):
-    shapes = [(20, 10), (10,), (3, 4, 5)]
+def gen_lrawhiten_case(name, T=4, seed=0, shapes=((20, 10), (10,), (3, 4, 5)), dtype=torch.float32, **kw):
+    shapes = [tuple(s) for s in shapes]
     out = {"T": np.asarray(T)}
     for k, v in kw.items():
         out["kw_" + k] = np.asarray(v if v is not None else float("nan"))
     g = torch.Generator().manual_seed(800 + seed)
-    params = [torch.nn.Parameter(0.5 * torch.randn(*s, generator=g)) for s in shapes]
+    params = [torch.nn.Parameter((0.5 * torch.randn(*s, generator=g)).to(dtype)) for s in shapes]
     for i, p in enumerate(params):
         out[f"p{i}_init"] = npy(p.data)
     torch.manual_seed(4000 + seed)
@@ -651,7 +651,7 @@ def gen_lrawhiten_case(name, T=4, seed=0, **kw):
         opt = psgd.LRAWhiten(params, **kw)
     out["U0"], out["V0"] = npy(opt._UVd[0]), npy(opt._UVd[1])
     for t in range(T):
-        cs = [(0.5 + i) * torch.randn(*s, generator=g) for i, s in enumerate(shapes)]
+        cs = [((0.5 + i) * torch.randn(*s, generator=g)).to(dtype) for i, s in enumerate(shapes)]
         for i, c in enumerate(cs):
             out[f"t{t}_g{i}"] = npy(c)
 
@@ -689,11 +689,22 @@ def gen_lra():
     gen_lrawhiten_case("clip_last_r4", seed=4, rank_of_approximation=4, preconditioner_init_scale=3.0,
                        update_preconditioner_first=False, lr_params=0.01)
     gen_lrawhiten_case("momentum_r32", seed=3, rank_of_approximation=32, preconditioner_init_scale=1.0, momentum=0.9)
+    gen_lrawhiten_bf16()
+
+
+def gen_lrawhiten_bf16():
+    # bf16 parameters (the reference keeps U, V, d in the parameter dtype: psgd.py:1113-1128), N = 1710 >= 512, even rank: the HIP engine's packed
+    # two-rows-per-thread passes (csrc/kernels_lra_pk.hiph) over three whole blocks + a 174-row tail; momentum, both update orders
+    gen_lrawhiten_case("bf16_r10_n1710", T=4, seed=11, shapes=((40, 30), (30,), (6, 8, 10)), dtype=torch.bfloat16,
+                       rank_of_approximation=10, preconditioner_init_scale=1.0, momentum=0.9, lr_params=0.01)
+    gen_lrawhiten_case("bf16_r4_n1710_last", T=4, seed=12, shapes=((40, 30), (30,), (6, 8, 10)), dtype=torch.bfloat16,
+                       rank_of_approximation=4, preconditioner_init_scale=None, update_preconditioner_first=False, lr_params=0.01)
 
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
     groups = {"helpers": gen_helpers, "kron": gen_kron, "kron_eq": gen_kron_eq, "kron_geoms": gen_kron_geoms,
-              "kron_pro4p": gen_kron_pro4p, "kwns4": gen_kwns4, "kronwhiten": gen_kronwhiten, "lra": gen_lra}
+              "kron_pro4p": gen_kron_pro4p, "kwns4": gen_kwns4, "kronwhiten": gen_kronwhiten, "lra": gen_lra,
+              "lrawhiten_bf16": gen_lrawhiten_bf16}
     for name in (sys.argv[1:] or list(groups)):       # no argument: everything
         groups[name]()

@@ -63,12 +63,21 @@ def test_lrawhiten_step_vs_golden(name):
                 kw[nm] = int(v)
             else:
                 kw[nm] = None if np.isnan(float(v)) else float(v)
-    params = [torch.nn.Parameter(T(z[f"p{i}_init"], torch.float32).to(DEV)) for i in range(3)]
+    # lrawhiten_bf16_*: bf16 parameters, N = 1710, even rank -- the packed row passes (kernels_lra_pk.hiph) inside the optimizer.  Yardstick as
+    # for every bf16 comparison: the fp64 oracle on the same bf16-rounded inputs and recorded draws is the truth, the reference's own bf16
+    # result (the golden) sets the scale: HIP error <= 1.5 x its error + one bf16 ulp.
+    bf = name.startswith("lrawhiten_bf16")
+    dt = torch.bfloat16 if bf else torch.float32
+    params = [torch.nn.Parameter(T(z[f"p{i}_init"], dt).to(DEV)) for i in range(3)]
     opt = lra.LRAWhiten(params, **kw)
     opt._UVd[0].copy_(T(z["U0"], torch.float32))       # the reference's own random init, replayed
     opt._UVd[1].copy_(T(z["V0"], torch.float32))
+    if bf:
+        okw = {k: v for k, v in kw.items() if k != "rank_of_approximation"}
+        p64 = [T(z[f"p{i}_init"], torch.float64).clone() for i in range(3)]
+        o64 = orc.LRAWhitenOracle(p64, T(z["U0"], torch.float64), T(z["V0"], torch.float64), **okw)
     for t in range(Tn):
-        cs = [T(z[f"t{t}_g{i}"], torch.float32).to(DEV) for i in range(3)]
+        cs = [T(z[f"t{t}_g{i}"], dt).to(DEV) for i in range(3)]
         nd = int(z[f"t{t}_ndraws"])
         draws = [z[f"t{t}_draw{k}"] for k in range(nd)]
         u = iter([float(draws[0])] + ([float(draws[2])] if nd > 1 else []))
@@ -78,10 +87,22 @@ def test_lrawhiten_step_vs_golden(name):
         def closure():
             return sum((p * c).sum() for p, c in zip(params, cs))
         opt.step(closure)
+        if not bf:
+            for i in range(3):
+                assert relerr(params[i].data, z[f"t{t}_p{i}"]) <= 2e-6 * (t + 1), (name, t, i)
+            for k, nm in enumerate(("U", "V", "d")):
+                assert relerr(opt._UVd[k], z[f"t{t}_{nm}"]) <= 5e-5 * (t + 1), (name, t, nm)
+            continue
+        o64.step([T(z[f"t{t}_g{i}"], torch.float64) for i in range(3)], float(draws[0]),
+                 T(draws[1], torch.float64) if nd > 1 else None, float(draws[2]) if nd > 1 else None)
+        if nd > 1:
+            assert opt._UVd[2]._psgdk_lra.info()["packed_rows"] == 1536
         for i in range(3):
-            assert relerr(params[i].data, z[f"t{t}_p{i}"]) <= 2e-6 * (t + 1), (name, t, i)
+            e_hip, e_ref = relerr(params[i].data, p64[i]), relerr(z[f"t{t}_p{i}"], p64[i])
+            assert e_hip <= 1.5 * e_ref + 7.8125e-3, (name, t, i, e_hip, e_ref)
         for k, nm in enumerate(("U", "V", "d")):
-            assert relerr(opt._UVd[k], z[f"t{t}_{nm}"]) <= 5e-5 * (t + 1), (name, t, nm)
+            e_hip, e_ref = relerr(opt._UVd[k], o64.UVd[k]), relerr(z[f"t{t}_{nm}"], o64.UVd[k])
+            assert e_hip <= 1.5 * e_ref + 7.8125e-3, (name, t, nm, e_hip, e_ref)
 
 
 def test_lra_known_answer():

@@ -252,10 +252,14 @@ def test_lrawhiten_step(name):
                 continue
             else:
                 kw[nm] = None if np.isnan(float(v)) else float(v)
-    params = [T(z[f"p{i}_init"], torch.float32).clone() for i in range(3)]
-    opt = orc.LRAWhitenOracle(params, T(z["U0"], torch.float32), T(z["V0"], torch.float32), **kw)
+    # (lrawhiten_bf16_*: bf16 parameters -- the reference keeps U, V, d and the momentum in the parameter dtype; the oracle in bf16 against the
+    #  reference in bf16: torch's CPU bf16 arithmetic on both sides, differences only where the contraction order differs)
+    dt = torch.bfloat16 if name.startswith("lrawhiten_bf16") else torch.float32
+    tol_p, tol_q = (1e-6, 2e-5) if dt == torch.float32 else (1e-3, 5e-3)      # (measured here: 0.0 -- the same bits)
+    params = [T(z[f"p{i}_init"], dt).clone() for i in range(3)]
+    opt = orc.LRAWhitenOracle(params, T(z["U0"], dt), T(z["V0"], dt), **kw)
     for t in range(Tn):
-        grads = [T(z[f"t{t}_g{i}"], torch.float32) for i in range(3)]
+        grads = [T(z[f"t{t}_g{i}"], dt) for i in range(3)]
         nd = int(z[f"t{t}_ndraws"])
         kinds = [str(z[f"t{t}_draw{k}_kind"]) for k in range(nd)]
         gate_u = float(z[f"t{t}_draw0"])
@@ -263,12 +267,12 @@ def test_lrawhiten_step(name):
         v_noise = coin = None
         if nd > 1:
             assert kinds[1:] == ["randn", "rand"]
-            v_noise, coin = T(z[f"t{t}_draw1"], torch.float32), float(z[f"t{t}_draw2"])
+            v_noise, coin = T(z[f"t{t}_draw1"], dt), float(z[f"t{t}_draw2"])
         opt.step(grads, gate_u, v_noise, coin)
         for i in range(3):
-            assert relerr(params[i], z[f"t{t}_p{i}"]) <= 1e-6
+            assert relerr(params[i], z[f"t{t}_p{i}"]) <= tol_p, (name, t, i, relerr(params[i], z[f"t{t}_p{i}"]))
         for k, nm in enumerate(("U", "V", "d")):
-            assert relerr(opt.UVd[k], z[f"t{t}_{nm}"]) <= 2e-5
+            assert relerr(opt.UVd[k], z[f"t{t}_{nm}"]) <= tol_q, (name, t, nm, relerr(opt.UVd[k], z[f"t{t}_{nm}"]))
 
 
 def kronwhiten_kw_from_golden(z):
