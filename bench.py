@@ -187,6 +187,9 @@ def bench_lra(args):
         one_step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / args.steps
+    packed = UVd[2]._psgdk_lra.info()["packed_rows"]          # psgdk_lra_info: which row kernels the last call took
+    row_kernels = (f"packed two-rows-per-thread passes (csrc/kernels_lra_pk.hiph) over {packed} rows, one-row kernels over the last {N - packed}"
+                   if packed else "one-row kernels (csrc/kernels_lra.hiph)")
     bytes_alg = (12 + 3) * N * r * esz + (18 + 3) * N * esz    # 9 R + 3 W + 3 R matrix passes, 18 + 3 N-vector passes
     # what the kernels move: 24 vector passes since round 3; since round 6 the Grams of psgd.py:1006 are carried from
     # update to update and the factors re-read for them every lra.GRAM_EVERY updates only: 2 of the 12 + 3 matrix passes run once in 16 updates
@@ -221,6 +224,7 @@ def bench_lra(args):
            "dtype": "bf16" if args.bf16 else "fp32", "data": "synthetic",
            "config": {"workload": f"ViT-B/16 parameter count N={N}, LRA rank {r}, {'bf16' if args.bf16 else 'fp32'}: update_precond_lra_whiten + precond_grad_lra",
                       "rank": r,
+                      "row_kernels": row_kernels,
                       "true_gram_passes_in_timed_region": (len([k for k in range(args.warmup, args.warmup + args.steps) if k % lra.GRAM_EVERY == 0])
                                                            if (lra.GRAM_EVERY and r <= 64) else args.steps),
                       "gram_recurrence": (f"the Grams of psgd.py:1006 carried from update to update (r x r recurrence), the factors re-read for them every "
