@@ -233,3 +233,48 @@ def test_random_lra_case_matches_oracle(seed):
                 assert relerr(UVd[k], Uo[k]) <= 2e-4, tag + (nm, relerr(UVd[k], Uo[k]))
         for k in range(3):
             assert relerr(Luvd[k], Lo[k]) <= 2e-4, tag + ("L", k)
+
+
+LB_CASES = int(os.environ.get("PSGDK_FUZZ_LRA_BF16", "16"))
+
+
+@pytest.mark.parametrize("seed", list(range(LB_CASES)))
+def test_random_lra_bf16_case_matches_oracle(seed):
+    """bf16 LRA update + apply with random N (whole 512-row blocks of the packed two-rows-per-thread passes plus a ragged tail, or too short
+    for them) and random rank (even ranks 2..16 take the packed passes, odd ones and 18..32 the one-row kernels); both update branches.
+    Truth: the fp64 oracle on the same bf16-rounded inputs and draws; yardstick: the oracle in bf16 (torch CPU bf16 arithmetic -- it reproduces
+    the reference's bf16 LRAWhiten goldens bit for bit, tests/test_oracle_golden.py): HIP error <= 1.5 x its error + one bf16 ulp."""
+    from psgd_torch_amd import lra
+    rnd = random.Random(9500 + seed)
+    N = rnd.choice([300, 512, 513, 1023, 1024, 1536 + 7, 4096, 5000, 12345, 65536 + 511])
+    r = rnd.choice([2, 4, 6, 8, 10, 12, 14, 16, 16, 10, 5, 7, 24])
+    bf = torch.bfloat16
+    gen = torch.Generator().manual_seed(9600 + seed)
+    U = torch.randn(N, r, generator=gen); V = torch.randn(N, r, generator=gen)
+    U = (U * (0.1 ** 0.5 / torch.linalg.vector_norm(U))).to(bf); V = (V * (0.1 ** 0.5 / torch.linalg.vector_norm(V))).to(bf)
+    d = (0.5 + torch.rand(N, 1, generator=gen)).to(bf)
+    UVd = [U.clone().to(DEV).contiguous(), V.clone().to(DEV).contiguous(), d.clone().to(DEV).contiguous()]
+    Luvd = [torch.zeros([], device=DEV) for _ in range(3)]
+    U64, L64 = [U.double(), V.double(), d.double()], [torch.zeros([], dtype=torch.float64) for _ in range(3)]
+    Ub, Lb = [U.clone(), V.clone(), d.clone()], [torch.zeros([], dtype=bf) for _ in range(3)]
+    want_packed = (N // 512 * 512) if (r % 2 == 0 and 2 <= r <= 16 and N >= 512) else 0
+    ULP = 7.8125e-3
+    for t in range(3):
+        g = ((0.5 + 2 * torch.rand(N, 1, generator=gen)) * torch.randn(N, 1, generator=gen)).to(bf)
+        vn = torch.randn(N, 1, generator=gen).to(bf)
+        coin = 0.25 if (t + seed) % 2 == 0 else 0.75
+        lra.update_precond_lra_whiten(UVd, Luvd, g.to(DEV), lr=0.1, betaL=0.9, damping=1e-6, v_noise=vn.to(DEV), coin=coin)
+        assert UVd[2]._psgdk_lra.info()["packed_rows"] == want_packed, (seed, N, r)
+        h = lra.precond_grad_lra(UVd, g.to(DEV))
+        orc.update_precond_lra_whiten(U64, L64, g.double(), vn.double(), coin, lr=0.1, betaL=0.9, damping=1e-6)
+        h64 = orc.precond_grad_lra(U64, g.double())
+        orc.update_precond_lra_whiten(Ub, Lb, g, vn, coin, lr=0.1, betaL=0.9, damping=1e-6)
+        hb = orc.precond_grad_lra(Ub, g)
+        tag = (seed, N, r, t)
+        assert torch.isfinite(h.float()).all(), tag
+        for nm, got, ref, truth in (("h", h, hb, h64), ("U", UVd[0], Ub[0], U64[0]), ("V", UVd[1], Ub[1], U64[1]), ("d", UVd[2], Ub[2], U64[2])):
+            e_hip, e_ref = relerr(got, truth), relerr(ref, truth)
+            assert e_hip <= 1.5 * e_ref + ULP, tag + (nm, e_hip, e_ref)
+        for k in range(3):
+            e_hip, e_ref = relerr(Luvd[k], L64[k]), relerr(Lb[k], L64[k])
+            assert e_hip <= 1.5 * e_ref + 2 * ULP, tag + ("L", k, e_hip, e_ref)
